@@ -1,0 +1,93 @@
+"""NIF asset helpers for tests and bench (numpy only; no device code).
+
+* `load_metadata` mirrors src/neural_networks/NifMetaData.cpp:11-71 (JSON fields, the -eps fold
+  into mean at :48-53, hidden size from `train_command` at :56-65).
+* `synthetic_nif` builds seeded stand-in weights: the trained weights
+  (nif_models/.../converted.hdf5) are missing from the reference checkout (.MISSING_LARGE_BLOBS)
+  and there is no HDF5 library here, so benchmarks and parity tests run on random-initialised
+  weights of the same architecture.
+"""
+import json
+
+import numpy as np
+
+# nif_models/urban_alley_01_4k_fp16_yuv/assets.extra/nif_metadata.txt:2-12,35-38
+URBAN_ALLEY_META = {
+    "embedding_dimension": 12,
+    "hidden_size": 320,
+    "layer_count": 6,
+    "eps": 1e-08,
+    "log_tone_map": True,
+    "max": 3.4299468994140625,
+    "mean": [-2.3514461517333984, -2.2660605907440186, -1.9648972749710083],
+    "original_image_shape": [2048, 4096, 3],
+}
+
+
+def load_metadata(path):
+    with open(path) as f:
+        pt = json.load(f)
+    enc = pt["encode_params"]
+    mean = [np.float32(m) for m in enc["mean"]]
+    eps = np.float32(enc["eps"])
+    log_tone_map = bool(enc["log_tone_map"])
+    if log_tone_map:  # NifMetaData.cpp:48-53
+        mean = [np.float32(m - eps) for m in mean]
+    hidden = layers = None
+    cmd = pt.get("train_command", [])
+    for i, tok in enumerate(cmd):
+        if tok == "--layer-size":
+            hidden = int(cmd[i + 1])
+        if tok == "--layer-count":
+            layers = int(cmd[i + 1])
+    return {
+        "name": pt["name"],
+        "embedding_dimension": int(pt["embedding_dimension"]),
+        "hidden_size": hidden,
+        "layer_count": layers,
+        "original_image_shape": [int(x) for x in pt["original_image_shape"]],
+        "eps": float(eps),
+        "log_tone_map": log_tone_map,
+        "max": float(np.float32(enc["max"])),
+        "mean_folded": [float(m) for m in mean],
+    }
+
+
+def folded_mean(meta=URBAN_ALLEY_META):
+    eps = np.float32(meta["eps"])
+    return [float(np.float32(np.float32(m) - eps)) for m in meta["mean"]]
+
+
+def synthetic_nif(hidden=320, layer_count=6, embedding_dim=12, seed=2024, bias_scale=0.05):
+    """Return [(kernel fp16 [in,out], bias fp16 [out], relu)], Keras-Dense layout (NifModel.cpp:375-401).
+
+    Architecture as inferred in SURVEY.md row A9: `layer_count` hidden ReLU layers of width `hidden`,
+    the Fourier-feature input re-concatenated at the middle layer (the shape mismatch that
+    NifModel.cpp:305-308 detects), and a linear 3-channel head.
+    """
+    rng = np.random.Generator(np.random.Philox(seed))
+    in_dim = 4 * embedding_dim
+    skip = layer_count // 2
+    layers = []
+    fan_in = in_dim
+    for l in range(layer_count):
+        if l == skip:
+            fan_in += in_dim
+        k = rng.standard_normal((fan_in, hidden), dtype=np.float32) * np.float32(np.sqrt(2.0 / fan_in))
+        b = rng.standard_normal(hidden, dtype=np.float32) * np.float32(bias_scale)
+        layers.append((k.astype(np.float16), b.astype(np.float16), True))
+        fan_in = hidden
+    k = rng.standard_normal((fan_in, 3), dtype=np.float32) * np.float32(0.25 * np.sqrt(2.0 / fan_in))
+    b = rng.standard_normal(3, dtype=np.float32) * np.float32(bias_scale)
+    layers.append((k.astype(np.float16), b.astype(np.float16), False))
+    return layers
+
+
+def flops_per_sample(layers):
+    """NifModel::analyseModel (NifModel.cpp:129-133)."""
+    f = 0
+    for k, b, _ in layers:
+        f += 2 * k.shape[0] * k.shape[1]
+        if b is not None:
+            f += k.shape[1]
+    return f
