@@ -1,0 +1,161 @@
+/*
+ * ptmi.h -- C-ABI of the MI355X path-trace hot path (libptmi.so).
+ *
+ * Drop-in boundary for markp-gc/ipu_path_trace: each entry point replaces one of the five
+ * named Poplar programs / named data streams that PathTracerApp::execute() drives
+ * (reference: src/PathTracerApp.cpp:479-483 registers the programs, src/ipu_utils.hpp:288-373
+ * StreamableTensor is the stream mechanism).  Plain pointers and sizes only; no C++ or torch
+ * types cross this boundary.  All functions return 0 on success and a negative pt_status
+ * otherwise; pt_last_error() returns the message (the reference throws std::runtime_error /
+ * std::logic_error which GraphManager::run catches once, src/ipu_utils.hpp:532-535 -- the C++
+ * shim in ipu_path_trace_amd/host re-throws from these codes).
+ *
+ * Threading (as the reference, PathTracerApp.cpp:692-709): calls on one handle are made from one
+ * thread, strictly setup -> path_trace -> read_results; the library copies from / to the host
+ * buffers synchronously and retains no host pointer after returning.
+ */
+#ifndef PTMI_H
+#define PTMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTMI_ABI_VERSION 1
+
+typedef struct pt_context* pt_handle;
+
+/* Wire format of the `trace_buffer` stream: src/codelets/TraceRecord.hpp:7-19
+ * (20 bytes; offsets 0/2/4/8/12/16/18).  Padding items carry u = v = 65535
+ * (src/LoadBalancer.cpp:66-71) and are traced like any other item. */
+typedef struct pt_trace_record {
+  uint16_t u, v;
+  float r, g, b;
+  uint16_t sampleCount;
+  uint16_t pathLength;
+} pt_trace_record;
+
+enum pt_status {
+  PT_OK = 0,
+  PT_ERR_INVALID_ARGUMENT = -1,
+  PT_ERR_NO_DEVICE = -2,
+  PT_ERR_HIP = -3,
+  PT_ERR_UNSUPPORTED_MODEL = -4,
+  PT_ERR_NOT_READY = -5,
+  PT_ERR_OUT_OF_MEMORY = -6
+};
+
+enum { PT_AA_NORMAL = 0, PT_AA_UNIFORM = 1, PT_AA_TRUNCATED_NORMAL = 2 }; /* PathTracerApp.cpp:29-45 */
+enum { PT_SAMPLES_HALF = 0, PT_SAMPLES_FLOAT = 1 };                        /* PathTracerApp.cpp:297 */
+enum { PT_DTYPE_F16 = 0 };
+
+/* Compile-time parameters of the reference graph: the CLI options consumed by
+ * PathTracerApp::build() and IpuPathTraceJob::buildGraph() (PathTracerApp.cpp:799-817,
+ * IpuPathTraceJob.cpp:95-138). */
+typedef struct pt_config {
+  uint32_t struct_size;          /* sizeof(pt_config) */
+  uint32_t width, height;        /* --width/--height */
+  uint32_t max_path_length;      /* --max-path-length (1..64) */
+  uint32_t roulette_depth;       /* --roulette-depth (>= 1) */
+  float stop_prob;               /* --stop-prob, rounded to half as on the IPU */
+  float refractive_index;        /* --refractive-index, rounded to half as on the IPU */
+  int32_t aa_noise_type;         /* --aa-noise-type */
+  int32_t sample_precision;      /* PT_SAMPLES_HALF reproduces the IPU's half primary samples */
+  int32_t device;                /* HIP device ordinal (the role of --ipus device selection) */
+  uint32_t max_work_items;       /* capacity of the trace buffer (tiles x rays-per-tile) */
+  uint32_t iterations_per_batch; /* sample iterations fused per kernel batch; 0 = auto */
+  void* stream;                  /* hipStream_t to run on, or NULL for a private stream */
+} pt_config;
+
+/* One dense layer as NifModel streams it (src/neural_networks/DenseLayer.hpp:18-31,
+ * NifModel.cpp:375-401): kernel row-major [rows = in][cols = out], bias [cols] or NULL,
+ * raw fp16 bytes as stored in the Keras H5. */
+typedef struct pt_layer {
+  uint32_t rows, cols;
+  const void* kernel;
+  const void* bias;
+  int32_t dtype;                 /* PT_DTYPE_F16 */
+  int32_t relu;                  /* activation == "relu" (NifModel.cpp:323-325) */
+} pt_layer;
+
+/* Replaces the three cycle-count streams (PathTracerApp.cpp:598-603) with per-stage device
+ * times from HIP events, plus the counters the roofline accounting needs. */
+typedef struct pt_stats {
+  uint64_t paths;                /* path-samples traced by the last path_trace */
+  uint64_t segments;             /* sum of pathLength (LoadBalancer.cpp:198-213 "totalRays") */
+  uint64_t escaped;              /* paths that reached the environment light = NIF evaluations */
+  uint64_t nif_flops_per_sample; /* NifModel::analyseModel formula (NifModel.cpp:129-133) */
+  double path_trace_ms;          /* sum over trace-kernel launches  (path_trace_cycle_count) */
+  double nif_ms;                 /* sum over NIF-kernel launches    (nif_cycle_count) */
+  double accumulate_ms;          /* sum over accumulate launches */
+  double total_ms;               /* whole path_trace program        (iter_cycle_count x iterations) */
+  uint32_t trace_launches, nif_launches, accumulate_launches;
+  uint32_t reserved;
+} pt_stats;
+
+/* One traced path, for kernel-level parity checks: the information the reference keeps in the
+ * per-ray contribution stack (PathTracerApp.cpp:301-308) reduced to what the deferred stages use. */
+typedef struct pt_path_record {
+  uint32_t length;               /* contribution-stack size incl. terminator (codelets.cpp:253) */
+  uint32_t escaped;
+  float dir[3];                  /* ESCAPED record direction (codelets.cpp:187) */
+  float uv[2];                   /* PreProcessEscapedRays output (codelets.cpp:343-347) */
+  float throughput[3];           /* product of clr*weight along the path incl. terminal weight */
+  float cam[2];                  /* GenerateCameraRays output, half-rounded (codelets.cpp:74-75) */
+} pt_path_record;
+
+/* Construct the renderer: the work PathTracerApp::build() + GraphManager compile/load do
+ * (PathTracerApp.cpp:310-484, ipu_utils.hpp:473-551).  Fails if no HIP device is usable. */
+int pt_create(const pt_config* config, pt_handle* out);
+int pt_destroy(pt_handle h);
+/* Message for the last failure on `h` (or, with h == NULL, of the last failed pt_create). */
+const char* pt_last_error(pt_handle h);
+int pt_abi_version(void);
+
+/* Program "init_nif_weights" (PathTracerApp.cpp:480; streams NifModel.cpp:375-401): all layer
+ * kernels and biases, `max`, and `mean` with -eps already folded in (NifMetaData.cpp:48-53).
+ * May be called again to hot-swap the environment (PathTracerApp.cpp:548-557). */
+int pt_upload_nif(pt_handle h, const pt_layer* layers, uint32_t n_layers, uint32_t embedding_dim,
+                  float max, const float mean[3], int32_t log_tonemap);
+/* Constant-radiance environment instead of a NIF (BASELINE config C1; no reference program). */
+int pt_set_constant_env(pt_handle h, const float rgb[3]);
+
+/* Program "init_render_settings" (PathTracerApp.cpp:479): streams seed u32[2], anti_alias_scale
+ * (half), field_of_view (half, radians), hdri_azimuth (f32, radians), on_device_sample_limit.
+ * A new seed restarts the sample-index sequence; the same seed continues it. */
+int pt_set_render_settings(pt_handle h, uint64_t seed, float aa_noise_scale, float fov_radians,
+                           float azimuth_radians, uint32_t samples_per_step);
+
+/* Program "setup" (PathTracerApp.cpp:481): host -> device copy of the active worklist. */
+int pt_setup(pt_handle h, const pt_trace_record* work, size_t n);
+/* Program "path_trace" (PathTracerApp.cpp:482): samples_per_step iterations of
+ * K2..K12 on the device (PathTracerApp.cpp:432-468).  Blocks until the device is done. */
+int pt_path_trace(pt_handle h);
+/* Program "read_results" (PathTracerApp.cpp:483): device -> host copy of the worklist plus stats. */
+int pt_read_results(pt_handle h, pt_trace_record* work, size_t n, pt_stats* stats);
+/* Stats of the last path_trace without the device -> host copy. */
+int pt_get_stats(pt_handle h, pt_stats* stats);
+
+/* Multi-GPU film hand-off: write mean radiance per work item, BGR float32 [n][3] (the value
+ * AccumulatedImage::accumulate adds, AccumulatedImage.cpp:59-74: (b,g,r)/sampleCount), into a
+ * DEVICE buffer on the handle's stream so the caller can gather HDR tiles with RCCL. */
+int pt_export_hdr_device(pt_handle h, void* device_bgr, size_t n);
+/* Clear r,g,b,sampleCount,pathLength on the device worklist
+ * (LoadBalancer::clearInactiveAccumulators, LoadBalancer.cpp:198-213) without a host round trip. */
+int pt_clear_accumulators(pt_handle h);
+int pt_synchronize(pt_handle h);
+
+/* Standalone NIF inference, host buffers: u, v in [0,1) -> decoded BGR float32 [n][3]
+ * (NifModel's streamed-IO mode, NifModel.cpp:268-278,338-350). */
+int pt_nif_infer(pt_handle h, const float* u, const float* v, size_t n, float* bgr);
+/* Trace individual paths (pixel u,v; absolute sample index) and return their records. */
+int pt_trace_paths(pt_handle h, const uint16_t* u, const uint16_t* v, const uint32_t* sample_index,
+                   size_t n, pt_path_record* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTMI_H */

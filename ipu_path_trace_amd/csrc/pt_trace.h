@@ -1,0 +1,358 @@
+// pt_trace.h -- the per-pixel sampling loop as a persistent-threads HIP kernel.
+//
+// Replaces the reference's GenerateCameraRays / RayTraceKernel / PreProcessEscapedRays codelets
+// (src/codelets/codelets.cpp:36-80, :93-227, :312-358) and the poprand noise tensors
+// (src/PathTracerApp.cpp:266-299).  One lane carries one path in registers; a lane whose path
+// ends is refilled from the wave's share of the batch (wave ballot + mbcnt prefix), and escaped
+// paths are appended to the workgroup's region of the NIF queue (ballot + one LDS atomic per
+// wave), so the queue the MFMA kernel reads is dense and no ray state ever goes to HBM.
+#pragma once
+#include "pt_device_math.h"
+
+namespace ptd {
+
+enum { MAT_DIFFUSE = 0, MAT_SPECULAR = 1, MAT_REFRACTIVE = 2 };
+constexpr int kNumObjects = 6;
+constexpr float kEps = 1e-5f;           // INFERRED intersection epsilon (< 1e-4 clear-coat gap)
+constexpr float kInf = 3.402823466e+38f;
+constexpr float kPi = 3.1415927410125732421875f;
+
+// Scene of src/codelets/codelets.cpp:111-144 as kernel-argument data (wave-uniform -> SGPRs).
+struct SceneObject {
+  float cx, cy, cz;     // centre
+  float radius, r2;     // r2 = radius*radius
+  float nx, ny, nz;     // disc normal
+  float colr, colg, colb;
+  int32_t type;         // MAT_*
+  int32_t is_disc;
+};
+
+struct TraceParams {
+  SceneObject obj[kNumObjects];
+  float width_f, height_f;   // image size as float (pixelToRay)
+  float tx, ty;              // tan(fov/2), (h/w) tan(fov/2)
+  float aa_scale;            // half-rounded
+  float stop_prob;           // half-rounded
+  float rr_factor;           // 1 / (1 - stop_prob)
+  float ri;                  // half-rounded refractive index
+  float azimuth;
+  uint32_t seed_lo, seed_hi;
+  uint32_t sample_base;      // absolute index of iteration 0 of this batch
+  uint32_t max_path_length, roulette_depth;
+  int32_t aa_type, samples_half;
+  uint32_t n_items, total_paths;  // total_paths = n_items * iterations in this batch
+  uint32_t n_waves;          // waves in the grid (chunk stride)
+  uint32_t region_cap;       // queue slots owned by one workgroup
+  int32_t env_const;
+  float env_r, env_g, env_b;
+  const uint32_t* pix;       // [n_items] u | v<<16
+  float* q_u; float* q_v; float* q_tr; float* q_tg; float* q_tb; uint32_t* q_path;
+  uint32_t* region_count;    // [gridDim.x]
+  uint8_t* plen;             // [total_paths] length | escaped<<7
+  float* rad_r; float* rad_g; float* rad_b;  // [total_paths] (constant-env mode writes here)
+};
+
+struct PathState {
+  Vec3 o, d, T;
+  uint32_t pixel;    // u | v<<16
+  uint32_t sample;
+  uint32_t depth;
+};
+
+__device__ __forceinline__ float uniform01(uint32_t bits, int half_grid) {
+  return half_grid ? (float)(bits >> 21) * 4.8828125e-04f : (float)(bits >> 8) * 5.9604644775390625e-08f;
+}
+
+// poprand noise into a half tensor (PathTracerApp.cpp:29-45): Box-Muller on Philox block 0.
+__device__ __forceinline__ void aa_noise(const TraceParams& P, uint32_t pixel, uint32_t sample, float& n0, float& n1) {
+  uint32_t w[4];
+  philox4x32_10(pixel, sample, 0u, 0x5054u, P.seed_lo, P.seed_hi, w);
+  if (P.aa_type == 1) {
+    float a = (float)(w[0] >> 8) * 5.9604644775390625e-08f;
+    float b = (float)(w[1] >> 8) * 5.9604644775390625e-08f;
+    n0 = hround(2.0f * a - 1.0f);
+    n1 = hround(2.0f * b - 1.0f);
+    return;
+  }
+  float r0 = 0.f, r1 = 0.f;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    float u1 = (float)((w[2 * attempt] >> 8) + 1u) * 5.9604644775390625e-08f;
+    float u2 = (float)(w[2 * attempt + 1] >> 8) * 5.9604644775390625e-08f;
+    float rad = sqrtf(-2.0f * dm_log(u1));
+    float s, c;
+    dm_sincos2pi(u2, s, c);
+    r0 = rad * c;
+    r1 = rad * s;
+    if (P.aa_type == 2) {
+      bool bad = (fabsf(r0) > 3.0f) || (fabsf(r1) > 3.0f);
+      if (bad && attempt == 0) continue;
+      r0 = fminf(fmaxf(r0, -3.0f), 3.0f);
+      r1 = fminf(fmaxf(r1, -3.0f), 3.0f);
+    }
+    break;
+  }
+  n0 = hround(r0);
+  n1 = hround(r1);
+}
+
+// GenerateCameraRays::compute (codelets.cpp:68-75) + Ray ctor (:162-163).
+__device__ __forceinline__ void start_path(const TraceParams& P, uint32_t pixel, uint32_t sample, PathState& s,
+                                           float& camx, float& camy) {
+  float n0, n1;
+  aa_noise(P, pixel, sample, n0, n1);
+  float c = (float)(pixel & 0xffffu) + hround(P.aa_scale * n0);
+  float r = (float)(pixel >> 16) + hround(P.aa_scale * n1);
+  float px = ((2.0f * c - P.width_f) / P.width_f) * P.tx;
+  float py = -(((2.0f * r - P.height_f) / P.height_f) * P.ty);
+  camx = hround(px);
+  camy = hround(py);
+  s.o = mk(0.f, 0.f, 0.f);
+  s.d = normalise(mk(camx, camy, -1.f));
+  s.T = mk(1.f, 1.f, 1.f);
+  s.pixel = pixel;
+  s.sample = sample;
+  s.depth = 0;
+}
+
+__device__ __forceinline__ float sphere_intersect(Vec3 o, Vec3 d, const SceneObject& ob) {
+  Vec3 oc = sub(o, mk(ob.cx, ob.cy, ob.cz));
+  float b = 2.0f * dot(oc, d);
+  float c_ = dot(oc, oc) - ob.r2;
+  float disc = b * b - 4.0f * c_;
+  if (disc < 0.0f) return 0.0f;
+  disc = sqrtf(disc);
+  float sol1 = -b + disc;
+  float sol2 = -b - disc;
+  return (sol2 > kEps) ? sol2 * 0.5f : ((sol1 > kEps) ? sol1 * 0.5f : 0.0f);
+}
+
+__device__ __forceinline__ float disc_intersect(Vec3 o, Vec3 d, const SceneObject& ob) {
+  Vec3 n = mk(ob.nx, ob.ny, ob.nz), c = mk(ob.cx, ob.cy, ob.cz);
+  float denom = dot(n, d);
+  if (denom == 0.0f) return 0.0f;
+  float t = dot(sub(c, o), n) / denom;
+  if (!(t > kEps)) return 0.0f;
+  Vec3 p = add(o, scale(d, t));
+  Vec3 pc = sub(p, c);
+  if (dot(pc, pc) > ob.r2) return 0.0f;
+  return t;
+}
+
+enum StepResult { STEP_CONTINUE = 0, STEP_ESCAPED = 1, STEP_DEAD = 2 };
+
+// One iteration of the while loop of RayTraceKernel::compute (codelets.cpp:173-216) with the
+// AccumulateContributions fold (codelets.cpp:255-292) carried forward as throughput T.
+// Returns the path length (contribution-stack size, codelets.cpp:253) through `length` when the
+// path ends.
+__device__ __forceinline__ int bounce(const TraceParams& P, PathState& s, uint32_t& length) {
+  uint32_t w[4];
+  philox4x32_10(s.pixel, s.sample, 1u + s.depth, 0x5054u, P.seed_lo, P.seed_hi, w);
+  float rr = 1.0f;
+  if (s.depth >= P.roulette_depth) {                          // :176-180
+    float u = uniform01(w[0], P.samples_half);
+    if (u <= P.stop_prob) {
+      length = s.depth ? s.depth : 1u;                        // END overwrites the last record (:219-222)
+      return STEP_DEAD;
+    }
+    rr = P.rr_factor;
+  }
+  // Scene::intersect (:183): nearest hit in declaration order.
+  int best = -1;
+  float tbest = kInf;
+#pragma unroll
+  for (int i = 0; i < kNumObjects; ++i) {
+    float t = P.obj[i].is_disc ? disc_intersect(s.o, s.d, P.obj[i]) : sphere_intersect(s.o, s.d, P.obj[i]);
+    if (t > kEps && t < tbest) { tbest = t; best = i; }
+  }
+  if (best < 0) {                                             // :184-190 ESCAPED
+    s.T = scale(s.T, rr);
+    length = s.depth + 1u;
+    return STEP_ESCAPED;
+  }
+  // select the hit object's data (wave-uniform table, per-lane index)
+  float cx = 0, cy = 0, cz = 0, nx = 0, ny = 0, nz = 0, cr = 0, cg = 0, cb = 0;
+  int type = 0, is_disc = 0;
+#pragma unroll
+  for (int i = 0; i < kNumObjects; ++i) {
+    if (best == i) {
+      cx = P.obj[i].cx; cy = P.obj[i].cy; cz = P.obj[i].cz;
+      nx = P.obj[i].nx; ny = P.obj[i].ny; nz = P.obj[i].nz;
+      cr = P.obj[i].colr; cg = P.obj[i].colg; cb = P.obj[i].colb;
+      type = P.obj[i].type; is_disc = P.obj[i].is_disc;
+    }
+  }
+  Vec3 hp = add(s.o, scale(s.d, tbest));
+  s.o = hp;
+  Vec3 n = is_disc ? mk(nx, ny, nz) : normalise(sub(hp, mk(cx, cy, cz)));
+  if (type == MAT_DIFFUSE) {                                  // :199-204, light::diffuse
+    float u1 = uniform01(w[1], P.samples_half);
+    float u2 = uniform01(w[2], P.samples_half);
+    Vec3 rx, ry;
+    if (fabsf(n.x) > fabsf(n.y)) {
+      float inv = 1.0f / sqrtf(n.x * n.x + n.z * n.z);
+      rx = mk(-n.z * inv, 0.0f, n.x * inv);
+    } else {
+      float inv = 1.0f / sqrtf(n.y * n.y + n.z * n.z);
+      rx = mk(0.0f, n.z * inv, -n.y * inv);
+    }
+    ry = cross(n, rx);
+    float r = sqrtf(1.0f - u1 * u1);
+    float sn, cs;
+    dm_sincos2pi(u2, sn, cs);
+    Vec3 h = mk(cs * r, sn * r, u1);
+    s.d = mk(dot(mk(rx.x, ry.x, n.x), h), dot(mk(rx.y, ry.y, n.y), h), dot(mk(rx.z, ry.z, n.z), h));
+    float cost = dot(s.d, n);
+    s.T = scale(cwise(s.T, mk(cr, cg, cb)), cost * rr);
+  } else if (type == MAT_SPECULAR) {                          // :205-207, light::reflect
+    float cost = dot(s.d, n);
+    s.d = normalise(sub(s.d, scale(n, cost * 2.0f)));
+    s.T = scale(s.T, rr);
+  } else {                                                    // :208-213, light::refract
+    float u = uniform01(w[1], P.samples_half);
+    float nn = P.ri;
+    float r0 = (1.0f - nn) / (1.0f + nn);
+    r0 = r0 * r0;
+    if (dot(n, s.d) > 0.0f) { n = scale(n, -1.0f); nn = 1.0f / nn; }
+    nn = 1.0f / nn;
+    float cost1 = -dot(n, s.d);
+    float cost2 = 1.0f - nn * nn * (1.0f - cost1 * cost1);
+    float m = 1.0f - cost1;
+    float m2 = m * m;
+    float rprob = r0 + (1.0f - r0) * (m2 * m2 * m);
+    bool refracted = (cost2 > 0.0f && u > rprob);
+    if (refracted) s.d = normalise(add(scale(s.d, nn), scale(n, nn * cost1 - sqrtf(cost2))));
+    else s.d = normalise(add(s.d, scale(n, cost1 * 2.0f)));
+    Vec3 tint = refracted ? mk(cr, cg, cb) : mk(1.f, 1.f, 1.f);
+    s.T = scale(cwise(s.T, tint), 1.15f * rr);
+  }
+  s.depth += 1u;                                              // :215
+  if (s.depth >= P.max_path_length) {                         // stack full without an emitter (:173,:219-222)
+    length = s.depth;
+    return STEP_DEAD;
+  }
+  return STEP_CONTINUE;
+}
+
+// PreProcessEscapedRays::compute (codelets.cpp:333-347).
+__device__ __forceinline__ void dir_to_uv(Vec3 d, float azimuth, float& u, float& v) {
+  float theta = dm_acos(d.y);
+  float phi = dm_atan2(d.z, d.x) + azimuth;
+  const float twoPi = 2.f * kPi;
+  const float invPi = 1.f / kPi;
+  const float inv2Pi = 1.f / twoPi;
+  if (phi < 0.f) phi += twoPi;
+  else if (phi > twoPi) phi -= twoPi;
+  u = theta * invPi;
+  v = phi * inv2Pi;
+}
+
+constexpr int kTraceBlock = 256;
+constexpr uint32_t kRefillThreshold = 20;  // refill once this many lanes are idle (or none is active)
+
+__global__ __launch_bounds__(kTraceBlock) void trace_kernel(const TraceParams P) {
+  __shared__ uint32_t wg_count;
+  if (threadIdx.x == 0) wg_count = 0;
+  __syncthreads();
+
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t gw = blockIdx.x * (kTraceBlock / 64) + (threadIdx.x >> 6);
+  const uint32_t region_base = blockIdx.x * P.region_cap;
+  uint32_t cursor = 0;  // next unassigned j of this wave's strided path sequence
+  // paths this wave owns: j -> idx = ((j / 64) * n_waves + gw) * 64 + (j % 64)
+  const uint32_t n_chunks = (P.total_paths + 63u) / 64u;
+  const uint32_t my_chunks = (n_chunks > gw) ? (n_chunks - gw + P.n_waves - 1u) / P.n_waves : 0u;
+  const uint32_t my_paths = my_chunks * 64u;
+
+  PathState st;
+  uint32_t idx = 0;
+  bool active = false;
+
+  while (true) {
+    const uint64_t act_mask = __ballot(active);
+    const uint32_t n_active = (uint32_t)__popcll(act_mask);
+    const bool more = cursor < my_paths;
+    if (!more && n_active == 0) break;
+    if (more && (n_active == 0 || 64u - n_active >= kRefillThreshold)) {
+      // hand the next paths of the wave's sequence to the idle lanes (ballot + prefix count)
+      const uint64_t idle = ~act_mask;
+      const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+      if (!active) {
+        const uint32_t j = cursor + rank;
+        const uint32_t cand = ((j >> 6) * P.n_waves + gw) * 64u + (j & 63u);
+        if (j < my_paths && cand < P.total_paths) {
+          idx = cand;
+          const uint32_t item = cand % P.n_items;
+          const uint32_t iter = cand / P.n_items;
+          float camx, camy;
+          start_path(P, P.pix[item], P.sample_base + iter, st, camx, camy);
+          active = true;
+        }
+      }
+      cursor += 64u - n_active;
+    }
+    int res = STEP_CONTINUE;
+    uint32_t length = 0;
+    if (active) res = bounce(P, st, length);
+    const bool ended = active && res != STEP_CONTINUE;
+    const bool escaped = active && res == STEP_ESCAPED;
+    if (ended) {
+      P.plen[idx] = (uint8_t)(length | (escaped ? 0x80u : 0u));
+      active = false;
+    }
+    if (P.env_const) {
+      if (escaped) {  // constant environment: total = env (.) T, no NIF
+        P.rad_r[idx] = P.env_r * st.T.x;
+        P.rad_g[idx] = P.env_g * st.T.y;
+        P.rad_b[idx] = P.env_b * st.T.z;
+      }
+    } else {
+      const uint64_t esc_mask = __ballot(escaped);
+      if (esc_mask) {
+        uint32_t base = 0;
+        if (lane == (uint32_t)__ffsll((long long)esc_mask) - 1u) base = atomicAdd(&wg_count, (uint32_t)__popcll(esc_mask));
+        base = __shfl(base, __ffsll((long long)esc_mask) - 1, 64);
+        if (escaped) {
+          const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(esc_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)esc_mask, 0u));
+          const uint32_t q = region_base + base + rank;
+          float u, v;
+          dir_to_uv(st.d, P.azimuth, u, v);
+          P.q_u[q] = u; P.q_v[q] = v;
+          P.q_tr[q] = st.T.x; P.q_tg[q] = st.T.y; P.q_tb[q] = st.T.z;
+          P.q_path[q] = idx;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) P.region_count[blockIdx.x] = wg_count;
+}
+
+struct PathRecordOut {  // layout of pt_path_record (include/ptmi.h)
+  uint32_t length, escaped;
+  float dir[3], uv[2], throughput[3], cam[2];
+};
+
+// One thread per requested path; same device functions as trace_kernel.
+__global__ void trace_paths_kernel(const TraceParams P, const uint16_t* u, const uint16_t* v, const uint32_t* sample,
+                                   uint32_t n, PathRecordOut* out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  PathState st;
+  float camx, camy;
+  start_path(P, (uint32_t)u[i] | ((uint32_t)v[i] << 16), sample[i], st, camx, camy);
+  uint32_t length = 0;
+  int res;
+  do { res = bounce(P, st, length); } while (res == STEP_CONTINUE);
+  PathRecordOut r = {};
+  r.length = length;
+  r.escaped = (res == STEP_ESCAPED);
+  r.cam[0] = camx; r.cam[1] = camy;
+  if (r.escaped) {
+    r.dir[0] = st.d.x; r.dir[1] = st.d.y; r.dir[2] = st.d.z;
+    dir_to_uv(st.d, P.azimuth, r.uv[0], r.uv[1]);
+    r.throughput[0] = st.T.x; r.throughput[1] = st.T.y; r.throughput[2] = st.T.z;
+  }
+  out[i] = r;
+}
+
+}  // namespace ptd

@@ -1,0 +1,695 @@
+// ptmi.hip -- implementation of include/ptmi.h: device state, weight packing, kernel launches.
+//
+// Build (see __graft_entry__.build): hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC
+// -ffp-contract=off is part of the numerical contract (pt_device_math.h).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ptmi.h"
+#include "pt_nif.h"
+#include "pt_trace.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+// ---- binary16 helpers on the host (weights arrive as raw fp16 bytes)
+inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+uint16_t host_f2h(float f) {
+  uint32_t x = f2u(f), sign = (x >> 16) & 0x8000u, ax = x & 0x7fffffffu;
+  if (ax >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | ((ax > 0x7f800000u) ? 0x200u : 0u));
+  if (ax >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);
+  if (ax < 0x33000001u) return (uint16_t)sign;
+  int e = (int)(ax >> 23) - 127;
+  uint32_t m = (ax & 0x7fffffu) | 0x800000u, shift, hexp;
+  if (e < -14) { shift = (uint32_t)(13 + (-14 - e)); hexp = 0; } else { shift = 13; hexp = (uint32_t)(e + 15); }
+  uint32_t q = m >> shift, rem = m & ((1u << shift) - 1u), halfway = 1u << (shift - 1);
+  if (rem > halfway || (rem == halfway && (q & 1u))) q += 1u;
+  uint32_t h = hexp == 0 ? q : ((hexp - 1u) << 10) + q;
+  return (uint16_t)(sign | h);
+}
+
+float host_h2f(uint16_t h) {
+  uint32_t sign = ((uint32_t)h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+  if (e == 0) {
+    if (m == 0) return u2f(sign);
+    float v = (float)m * 5.9604644775390625e-08f;
+    return sign ? -v : v;
+  }
+  if (e == 31) return u2f(sign | 0x7f800000u | (m << 13));
+  return u2f(sign | ((e + 112u) << 23) | (m << 13));
+}
+
+inline float host_hround(float f) { return host_h2f(host_f2h(f)); }
+
+struct HostLayer {
+  uint32_t rows, cols;
+  std::vector<uint16_t> kernel;  // [rows][cols]
+  std::vector<uint16_t> bias;    // [cols] or empty
+  bool relu;
+};
+
+}  // namespace
+
+struct pt_context {
+  pt_config cfg{};
+  std::string error;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int n_cus = 256;
+
+  // worklist
+  uint32_t n_items = 0;
+  uint32_t capacity = 0;
+  ptd::TraceRecordDev* d_records = nullptr;
+  ptd::Accum acc{};
+  unsigned long long* d_counters = nullptr;  // [0] segments, [1] escaped
+
+  // batch buffers
+  uint32_t iters_per_batch = 1;
+  size_t batch_paths_cap = 0;
+  float *q_u = nullptr, *q_v = nullptr, *q_tr = nullptr, *q_tg = nullptr, *q_tb = nullptr;
+  uint32_t* q_path = nullptr;
+  size_t queue_cap = 0;
+  uint32_t* region_count = nullptr;
+  uint8_t* plen = nullptr;
+  float *rad_r = nullptr, *rad_g = nullptr, *rad_b = nullptr;
+
+  // render settings
+  bool settings_valid = false;
+  uint64_t seed = 0;
+  float aa_scale = 0, fov = 0, azimuth = 0;
+  uint32_t samples_per_step = 0;
+  uint32_t sample_cursor = 0;  // absolute index of the next sample iteration
+
+  // environment
+  bool env_const = false;
+  float env_rgb[3] = {0, 0, 0};
+  bool nif_valid = false;
+  int nif_hidden = 0, nif_emb = 0;
+  ptd::NifParams nif{};
+  uint4* d_wpack = nullptr;
+  uint4* d_bpack = nullptr;
+  uint64_t nif_flops = 0;
+
+  // stats
+  pt_stats stats{};
+  std::vector<hipEvent_t> events;
+
+  // scratch for the standalone entry points
+  void* d_scratch = nullptr;
+  size_t scratch_bytes = 0;
+};
+
+namespace {
+
+#define PT_HIP(call)                                                                         \
+  do {                                                                                       \
+    hipError_t e_ = (call);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      h->error = std::string(#call) + ": " + hipGetErrorString(e_);                          \
+      return PT_ERR_HIP;                                                                     \
+    }                                                                                        \
+  } while (0)
+
+int fail(pt_handle h, int code, const std::string& msg) {
+  h->error = msg;
+  return code;
+}
+
+template <typename T>
+hipError_t dev_alloc(T** p, size_t count) {
+  return hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T));
+}
+
+int ensure_scratch(pt_handle h, size_t bytes) {
+  if (bytes <= h->scratch_bytes) return PT_OK;
+  if (h->d_scratch) PT_HIP(hipFree(h->d_scratch));
+  h->d_scratch = nullptr;
+  h->scratch_bytes = 0;
+  PT_HIP(hipMalloc(&h->d_scratch, bytes));
+  h->scratch_bytes = bytes;
+  return PT_OK;
+}
+
+// Scene constants of src/codelets/codelets.cpp:111-144.
+void fill_scene(ptd::TraceParams& P) {
+  const float gain = 2.f;  // :127
+  struct Src { int disc; float c[3]; float r; float col[3]; int type; };
+  const Src src[ptd::kNumObjects] = {
+      {0, {-1.8575f, -0.98714f, -3.6f}, 0.6f, {1.f * gain, .89f * gain, .55f * gain}, ptd::MAT_DIFFUSE},          // :112,:128,:137
+      {0, {0.74795f, -0.55f, -4.3816f}, 1.05f, {1.f, 1.f, 1.f}, ptd::MAT_SPECULAR},                                // :113,:138
+      {0, {1.9929f, -1.08666f, (float)-3.23}, 0.5f, {0.75f, 0.75f, 0.75f}, ptd::MAT_REFRACTIVE},                   // :114,:131,:139
+      {0, {(float)-0.19931, -1.183f, -2.75f}, 0.4f, {.8f * gain, .06f * gain, .391f * gain}, ptd::MAT_DIFFUSE},   // :115,:129,:140
+      {0, {(float)-0.19931, -1.183f, -2.75f}, 0.4001f, {1.f, 1.f, 1.f}, ptd::MAT_REFRACTIVE},                      // :116,:141
+      {1, {0.f, -1.6f, -5.22f}, 3.5f, {.98f * gain, .76f * gain, .66f * gain}, ptd::MAT_DIFFUSE},                  // :121,:130,:143
+  };
+  for (int i = 0; i < ptd::kNumObjects; ++i) {
+    ptd::SceneObject& o = P.obj[i];
+    o.cx = src[i].c[0]; o.cy = src[i].c[1]; o.cz = src[i].c[2];
+    o.radius = src[i].r;
+    o.r2 = src[i].r * src[i].r;
+    o.nx = 0.f; o.ny = src[i].disc ? 1.f : 0.f; o.nz = 0.f;
+    o.colr = src[i].col[0]; o.colg = src[i].col[1]; o.colb = src[i].col[2];
+    o.type = src[i].type;
+    o.is_disc = src[i].disc;
+  }
+}
+
+void fill_trace_params(pt_handle h, ptd::TraceParams& P) {
+  memset(&P, 0, sizeof(P));
+  fill_scene(P);
+  const pt_config& c = h->cfg;
+  const float w = (float)c.width, hgt = (float)c.height;
+  const float fov = host_hround(h->fov);        // field_of_view stream is half (PathTracerApp.cpp:591)
+  P.width_f = w;
+  P.height_f = hgt;
+  P.tx = tanf(fov * 0.5f);                      // light::pixelToRay (INFERRED, see oracle/pt_oracle.c)
+  P.ty = (hgt / w) * P.tx;
+  P.aa_scale = host_hround(h->aa_scale);        // anti_alias_scale stream is half (:590)
+  P.stop_prob = host_hround(c.stop_prob);       // IpuPathTraceJob.cpp:137
+  P.rr_factor = 1.0f / (1.0f - P.stop_prob);
+  P.ri = host_hround(c.refractive_index);       // IpuPathTraceJob.cpp:133
+  P.azimuth = h->azimuth;
+  P.seed_lo = (uint32_t)h->seed;
+  P.seed_hi = (uint32_t)(h->seed >> 32);
+  P.max_path_length = c.max_path_length;
+  P.roulette_depth = c.roulette_depth;
+  P.aa_type = c.aa_noise_type;
+  P.samples_half = (c.sample_precision == PT_SAMPLES_HALF);
+  P.env_const = h->env_const ? 1 : 0;
+  P.env_r = h->env_rgb[0]; P.env_g = h->env_rgb[1]; P.env_b = h->env_rgb[2];
+  P.pix = h->acc.pix;
+  P.q_u = h->q_u; P.q_v = h->q_v; P.q_tr = h->q_tr; P.q_tg = h->q_tg; P.q_tb = h->q_tb; P.q_path = h->q_path;
+  P.region_count = h->region_count;
+  P.plen = h->plen;
+  P.rad_r = h->rad_r; P.rad_g = h->rad_g; P.rad_b = h->rad_b;
+}
+
+// Trace-grid geometry for a batch of `total` paths.
+struct TraceGrid {
+  uint32_t blocks, n_waves, region_cap;
+};
+TraceGrid trace_grid(uint32_t total) {
+  const uint32_t n_chunks = (total + 63u) / 64u;
+  uint32_t blocks = (n_chunks + 3u) / 4u;
+  if (blocks > (uint32_t)ptd::kMaxRegions) blocks = ptd::kMaxRegions;
+  if (blocks == 0) blocks = 1;
+  TraceGrid g;
+  g.blocks = blocks;
+  g.n_waves = blocks * 4u;
+  g.region_cap = 4u * ((n_chunks + g.n_waves - 1u) / g.n_waves) * 64u;
+  return g;
+}
+
+// ---- NIF weight packing -------------------------------------------------------------------
+// Piece (l, j, s): the A operand of one v_mfma_f32_32x32x16_f16: lane (r = lane & 31, hh = lane >> 5)
+// holds W^T[32 j + r][k(hh, 0..7)], where k() is the k-step's map onto rows of the Keras kernel:
+//  * activation k-step s (from a previous accumulator tile t = s / 2, half s % 2):
+//      k = 32 t + 16 (s % 2) + 8 (e >> 2) + 4 hh + (e & 3)     (accumulator-as-operand order)
+//  * input k-step s' (Fourier features, NifModel.cpp:216 order [sin u, sin v, cos u, cos v]):
+//      k = base + (e < 4 ? 0 : 2E) + hh E + 4 s' + (e & 3), base = H for a concat layer, else 0
+int pack_nif(pt_handle h, const std::vector<HostLayer>& L, uint32_t E, std::vector<uint16_t>& wpack,
+             std::vector<uint16_t>& bpack, ptd::NifParams& N) {
+  const uint32_t n = (uint32_t)L.size();
+  if (n < 2 || n > ptd::kMaxLayers) return fail(h, PT_ERR_UNSUPPORTED_MODEL, "NIF must have 2..16 dense layers");
+  if (E == 0 || E % 4) return fail(h, PT_ERR_UNSUPPORTED_MODEL, "embedding dimension must be a multiple of 4");
+  const uint32_t in_dim = 4 * E, H = L[0].cols;
+  if (L[0].rows != in_dim) return fail(h, PT_ERR_UNSUPPORTED_MODEL, "first layer must take the 4*embedding Fourier features");
+  if (H % 32) return fail(h, PT_ERR_UNSUPPORTED_MODEL, "hidden size must be a multiple of 32");
+  if (L[n - 1].cols != 3) return fail(h, PT_ERR_UNSUPPORTED_MODEL, "NIF head must have 3 outputs (BGR)");
+  memset(&N, 0, sizeof(N));
+  N.n_layers = n;
+  uint32_t piece = 0, btile = 0;
+  for (uint32_t l = 0; l < n; ++l) {
+    const HostLayer& Y = L[l];
+    const bool head = (l == n - 1);
+    if (!head && Y.cols != H) return fail(h, PT_ERR_UNSUPPORTED_MODEL, "all hidden layers must have the same width");
+    bool concat = false;
+    uint32_t act_steps = 0;
+    if (l == 0) {
+      if (Y.rows != in_dim) return fail(h, PT_ERR_UNSUPPORTED_MODEL, "bad first layer shape");
+    } else if (Y.rows == H) {
+      act_steps = H / 16;
+    } else if (Y.rows == H + in_dim) {  // NifModel.cpp:305-308: x = concat(x, input)
+      act_steps = H / 16;
+      concat = true;
+    } else {
+      return fail(h, PT_ERR_UNSUPPORTED_MODEL, "layer input width is neither hidden nor hidden+features");
+    }
+    const uint32_t in_steps = (l == 0 || concat) ? E / 4 : 0;
+    const uint32_t ksteps = act_steps + in_steps;
+    const uint32_t ntiles = (Y.cols + 31) / 32;
+    N.piece_base[l] = piece;
+    N.bias_base[l] = btile;
+    if (concat) N.concat_mask |= 1u << l;
+    if (Y.relu) N.relu_mask |= 1u << l;
+    if (!Y.bias.empty()) N.bias_mask |= 1u << l;
+    wpack.resize((size_t)(piece + ntiles * ksteps) * 512, 0);
+    bpack.resize((size_t)(btile + ntiles) * 32, 0);
+    for (uint32_t j = 0; j < ntiles; ++j) {
+      for (uint32_t s = 0; s < ksteps; ++s) {
+        uint16_t* dst = &wpack[(size_t)(piece + j * ksteps + s) * 512];
+        for (uint32_t lane = 0; lane < 64; ++lane) {
+          const uint32_t r = lane & 31, hh = lane >> 5, col = 32 * j + r;
+          for (uint32_t e = 0; e < 8; ++e) {
+            uint32_t k;
+            if (s < act_steps) {
+              k = 32 * (s / 2) + 16 * (s % 2) + 8 * (e >> 2) + 4 * hh + (e & 3);
+            } else {
+              const uint32_t sp = s - act_steps;
+              k = (concat ? H : 0) + (e < 4 ? 0 : 2 * E) + hh * E + 4 * sp + (e & 3);
+            }
+            dst[lane * 8 + e] = (col < Y.cols) ? Y.kernel[(size_t)k * Y.cols + col] : (uint16_t)0;
+          }
+        }
+      }
+      // bias of n-tile j in accumulator order: lane half hh, register i -> row (i&3) + 8 (i>>2) + 4 hh
+      for (uint32_t hh = 0; hh < 2; ++hh)
+        for (uint32_t i = 0; i < 16; ++i) {
+          const uint32_t col = 32 * j + (i & 3) + 8 * (i >> 2) + 4 * hh;
+          bpack[(size_t)(btile + j) * 32 + hh * 16 + i] = (!Y.bias.empty() && col < Y.cols) ? Y.bias[col] : (uint16_t)0;
+        }
+    }
+    piece += ntiles * ksteps;
+    btile += ntiles;
+  }
+  return PT_OK;
+}
+
+template <int HID, int E>
+void launch_nif_t(pt_handle h, const ptd::NifParams& N, int blocks) {
+  hipLaunchKernelGGL((ptd::nif_kernel<HID, E, 2>), dim3(blocks), dim3(256), 0, h->stream, N);
+}
+
+int launch_nif(pt_handle h, const ptd::NifParams& N, int blocks) {
+  if (h->nif_emb == 12) {
+    switch (h->nif_hidden) {
+      case 64: launch_nif_t<64, 12>(h, N, blocks); return PT_OK;
+      case 128: launch_nif_t<128, 12>(h, N, blocks); return PT_OK;
+      case 256: launch_nif_t<256, 12>(h, N, blocks); return PT_OK;
+      case 320: launch_nif_t<320, 12>(h, N, blocks); return PT_OK;
+      default: break;
+    }
+  }
+  if (h->nif_emb == 4 && h->nif_hidden == 64) { launch_nif_t<64, 4>(h, N, blocks); return PT_OK; }
+  return fail(h, PT_ERR_UNSUPPORTED_MODEL, "no MFMA kernel instantiated for this NIF shape");
+}
+
+bool nif_shape_supported(uint32_t hidden, uint32_t emb) {
+  if (emb == 12 && (hidden == 64 || hidden == 128 || hidden == 256 || hidden == 320)) return true;
+  if (emb == 4 && hidden == 64) return true;
+  return false;
+}
+
+void free_batch_buffers(pt_handle h) {
+  (void)hipFree(h->q_u); (void)hipFree(h->q_v); (void)hipFree(h->q_tr); (void)hipFree(h->q_tg); (void)hipFree(h->q_tb); (void)hipFree(h->q_path);
+  (void)hipFree(h->region_count); (void)hipFree(h->plen); (void)hipFree(h->rad_r); (void)hipFree(h->rad_g); (void)hipFree(h->rad_b);
+  h->q_u = h->q_v = h->q_tr = h->q_tg = h->q_tb = nullptr; h->q_path = nullptr;
+  h->region_count = nullptr; h->plen = nullptr; h->rad_r = h->rad_g = h->rad_b = nullptr;
+}
+
+hipEvent_t get_event(pt_handle h, size_t i) {
+  while (h->events.size() <= i) {
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    h->events.push_back(e);
+  }
+  return h->events[i];
+}
+
+}  // namespace
+
+extern "C" {
+
+int pt_abi_version(void) { return PTMI_ABI_VERSION; }
+
+const char* pt_last_error(pt_handle h) { return h ? h->error.c_str() : g_create_error.c_str(); }
+
+int pt_create(const pt_config* cfg, pt_handle* out) {
+  if (!cfg || !out) { g_create_error = "null argument"; return PT_ERR_INVALID_ARGUMENT; }
+  *out = nullptr;
+  if (cfg->struct_size != sizeof(pt_config)) { g_create_error = "pt_config.struct_size mismatch"; return PT_ERR_INVALID_ARGUMENT; }
+  if (cfg->width == 0 || cfg->height == 0 || cfg->width > 65535 || cfg->height > 65535) {
+    g_create_error = "width/height must be in 1..65535 (TraceRecord coordinates are uint16)";
+    return PT_ERR_INVALID_ARGUMENT;
+  }
+  if (cfg->max_path_length == 0 || cfg->max_path_length > 64) { g_create_error = "max_path_length must be in 1..64"; return PT_ERR_INVALID_ARGUMENT; }
+  if (cfg->roulette_depth == 0) { g_create_error = "roulette_depth must be >= 1 (0 is undefined behaviour in the reference)"; return PT_ERR_INVALID_ARGUMENT; }
+  if (!(cfg->stop_prob >= 0.f && cfg->stop_prob < 1.f)) { g_create_error = "stop_prob must be in [0,1)"; return PT_ERR_INVALID_ARGUMENT; }
+  if (cfg->aa_noise_type < 0 || cfg->aa_noise_type > 2) { g_create_error = "invalid aa_noise_type"; return PT_ERR_INVALID_ARGUMENT; }
+  if (cfg->max_work_items == 0) { g_create_error = "max_work_items must be > 0"; return PT_ERR_INVALID_ARGUMENT; }
+
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count == 0) {
+    g_create_error = "no HIP device available: the MI355X path has no CPU fallback";
+    return PT_ERR_NO_DEVICE;
+  }
+  if (cfg->device < 0 || cfg->device >= count) { g_create_error = "device ordinal out of range"; return PT_ERR_INVALID_ARGUMENT; }
+
+  pt_handle h = new pt_context();
+  h->cfg = *cfg;
+  auto bail = [&](int code) { g_create_error = h->error; pt_destroy(h); return code; };
+#define PT_HIPC(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { h->error = std::string(#call) + ": " + hipGetErrorString(e_); return bail(PT_ERR_HIP); } } while (0)
+  PT_HIPC(hipSetDevice(cfg->device));
+  hipDeviceProp_t prop;
+  PT_HIPC(hipGetDeviceProperties(&prop, cfg->device));
+  h->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (cfg->stream) { h->stream = (hipStream_t)cfg->stream; }
+  else { PT_HIPC(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
+
+  const uint32_t n = cfg->max_work_items;
+  h->capacity = n;
+  uint32_t k = cfg->iterations_per_batch;
+  if (k == 0) { k = (uint32_t)((8u << 20) / n); if (k < 1) k = 1; if (k > 32) k = 32; }
+  if ((uint64_t)k * n >= (1ull << 31)) k = (uint32_t)(((1ull << 31) - 1) / n);
+  if (k == 0) { h->error = "max_work_items too large"; return bail(PT_ERR_INVALID_ARGUMENT); }
+  h->iters_per_batch = k;
+  h->batch_paths_cap = (size_t)k * n;
+
+  PT_HIPC(dev_alloc(&h->d_records, n));
+  PT_HIPC(dev_alloc(&h->acc.pix, n));
+  PT_HIPC(dev_alloc(&h->acc.r, n));
+  PT_HIPC(dev_alloc(&h->acc.g, n));
+  PT_HIPC(dev_alloc(&h->acc.b, n));
+  PT_HIPC(dev_alloc(&h->acc.count, n));
+  PT_HIPC(dev_alloc(&h->acc.length, n));
+  PT_HIPC(dev_alloc(&h->d_counters, 2));
+  const TraceGrid g = trace_grid((uint32_t)h->batch_paths_cap);
+  h->queue_cap = (size_t)g.blocks * g.region_cap;
+  PT_HIPC(dev_alloc(&h->q_u, h->queue_cap));
+  PT_HIPC(dev_alloc(&h->q_v, h->queue_cap));
+  PT_HIPC(dev_alloc(&h->q_tr, h->queue_cap));
+  PT_HIPC(dev_alloc(&h->q_tg, h->queue_cap));
+  PT_HIPC(dev_alloc(&h->q_tb, h->queue_cap));
+  PT_HIPC(dev_alloc(&h->q_path, h->queue_cap));
+  PT_HIPC(dev_alloc(&h->region_count, (size_t)ptd::kMaxRegions));
+  PT_HIPC(dev_alloc(&h->plen, h->batch_paths_cap));
+  PT_HIPC(dev_alloc(&h->rad_r, h->batch_paths_cap));
+  PT_HIPC(dev_alloc(&h->rad_g, h->batch_paths_cap));
+  PT_HIPC(dev_alloc(&h->rad_b, h->batch_paths_cap));
+#undef PT_HIPC
+  *out = h;
+  return PT_OK;
+}
+
+int pt_destroy(pt_handle h) {
+  if (!h) return PT_OK;
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  free_batch_buffers(h);
+  (void)hipFree(h->d_records);
+  (void)hipFree(h->acc.pix); (void)hipFree(h->acc.r); (void)hipFree(h->acc.g); (void)hipFree(h->acc.b); (void)hipFree(h->acc.count); (void)hipFree(h->acc.length);
+  (void)hipFree(h->d_counters);
+  (void)hipFree(h->d_wpack); (void)hipFree(h->d_bpack);
+  (void)hipFree(h->d_scratch);
+  for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
+  if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return PT_OK;
+}
+
+int pt_upload_nif(pt_handle h, const pt_layer* layers, uint32_t n_layers, uint32_t embedding_dim, float max,
+                  const float mean[3], int32_t log_tonemap) {
+  if (!h) return PT_ERR_INVALID_ARGUMENT;
+  if (!layers || !mean || n_layers == 0) return fail(h, PT_ERR_INVALID_ARGUMENT, "null NIF arguments");
+  std::vector<HostLayer> L(n_layers);
+  uint64_t flops = 0;
+  for (uint32_t l = 0; l < n_layers; ++l) {
+    if (layers[l].dtype != PT_DTYPE_F16) return fail(h, PT_ERR_UNSUPPORTED_MODEL, "only fp16 NIF weights are supported");
+    if (!layers[l].kernel || layers[l].rows == 0 || layers[l].cols == 0) return fail(h, PT_ERR_INVALID_ARGUMENT, "empty layer kernel");
+    L[l].rows = layers[l].rows;
+    L[l].cols = layers[l].cols;
+    L[l].relu = layers[l].relu != 0;
+    const uint16_t* kp = static_cast<const uint16_t*>(layers[l].kernel);
+    L[l].kernel.assign(kp, kp + (size_t)L[l].rows * L[l].cols);
+    if (layers[l].bias) {
+      const uint16_t* bp = static_cast<const uint16_t*>(layers[l].bias);
+      L[l].bias.assign(bp, bp + L[l].cols);
+    }
+    flops += 2ull * L[l].rows * L[l].cols + (layers[l].bias ? L[l].cols : 0);  // NifModel.cpp:129-133
+  }
+  const uint32_t hidden = L[0].cols;
+  if (!nif_shape_supported(hidden, embedding_dim))
+    return fail(h, PT_ERR_UNSUPPORTED_MODEL, "NIF shape (hidden " + std::to_string(hidden) + ", embedding " +
+                                                 std::to_string(embedding_dim) + ") has no MFMA kernel in this build");
+  std::vector<uint16_t> wpack, bpack;
+  ptd::NifParams N;
+  int rc = pack_nif(h, L, embedding_dim, wpack, bpack, N);
+  if (rc) return rc;
+  PT_HIP(hipSetDevice(h->cfg.device));
+  PT_HIP(hipStreamSynchronize(h->stream));
+  if (h->d_wpack) PT_HIP(hipFree(h->d_wpack));
+  if (h->d_bpack) PT_HIP(hipFree(h->d_bpack));
+  h->d_wpack = nullptr; h->d_bpack = nullptr;
+  PT_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_wpack), wpack.size() * 2));
+  PT_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_bpack), bpack.size() * 2));
+  PT_HIP(hipMemcpy(h->d_wpack, wpack.data(), wpack.size() * 2, hipMemcpyHostToDevice));
+  PT_HIP(hipMemcpy(h->d_bpack, bpack.data(), bpack.size() * 2, hipMemcpyHostToDevice));
+  N.wpack = h->d_wpack;
+  N.bpack = h->d_bpack;
+  N.max = max;
+  N.mean0 = mean[0]; N.mean1 = mean[1]; N.mean2 = mean[2];
+  N.log_tonemap = log_tonemap;
+  h->nif = N;
+  h->nif_hidden = (int)hidden;
+  h->nif_emb = (int)embedding_dim;
+  h->nif_flops = flops;
+  h->nif_valid = true;
+  h->env_const = false;
+  return PT_OK;
+}
+
+int pt_set_constant_env(pt_handle h, const float rgb[3]) {
+  if (!h) return PT_ERR_INVALID_ARGUMENT;
+  if (!rgb) return fail(h, PT_ERR_INVALID_ARGUMENT, "null rgb");
+  h->env_const = true;
+  memcpy(h->env_rgb, rgb, 12);
+  return PT_OK;
+}
+
+int pt_set_render_settings(pt_handle h, uint64_t seed, float aa, float fov, float azimuth, uint32_t spp) {
+  if (!h) return PT_ERR_INVALID_ARGUMENT;
+  if (spp == 0) return fail(h, PT_ERR_INVALID_ARGUMENT, "samples_per_step must be > 0");
+  if (!(fov > 0.f && fov < 3.14159f)) return fail(h, PT_ERR_INVALID_ARGUMENT, "fov must be in (0, pi) radians");
+  if (!h->settings_valid || seed != h->seed) h->sample_cursor = 0;
+  h->seed = seed; h->aa_scale = aa; h->fov = fov; h->azimuth = azimuth; h->samples_per_step = spp;
+  h->settings_valid = true;
+  return PT_OK;
+}
+
+int pt_setup(pt_handle h, const pt_trace_record* work, size_t n) {
+  if (!h) return PT_ERR_INVALID_ARGUMENT;
+  if (!work && n) return fail(h, PT_ERR_INVALID_ARGUMENT, "null worklist");
+  if (n > h->capacity) return fail(h, PT_ERR_INVALID_ARGUMENT, "worklist larger than max_work_items");
+  PT_HIP(hipSetDevice(h->cfg.device));
+  h->n_items = (uint32_t)n;
+  if (n == 0) return PT_OK;
+  static_assert(sizeof(pt_trace_record) == 20 && sizeof(ptd::TraceRecordDev) == 20, "TraceRecord wire format");
+  PT_HIP(hipMemcpyAsync(h->d_records, work, n * sizeof(pt_trace_record), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(ptd::unpack_records_kernel, dim3(((uint32_t)n + 255) / 256), dim3(256), 0, h->stream, h->d_records,
+                     (uint32_t)n, h->acc);
+  PT_HIP(hipGetLastError());
+  PT_HIP(hipStreamSynchronize(h->stream));  // host buffer is not touched after return
+  return PT_OK;
+}
+
+int pt_path_trace(pt_handle h) {
+  if (!h) return PT_ERR_INVALID_ARGUMENT;
+  if (!h->settings_valid) return fail(h, PT_ERR_NOT_READY, "pt_set_render_settings has not been called");
+  if (!h->env_const && !h->nif_valid) return fail(h, PT_ERR_NOT_READY, "no environment: call pt_upload_nif or pt_set_constant_env");
+  PT_HIP(hipSetDevice(h->cfg.device));
+  memset(&h->stats, 0, sizeof(h->stats));
+  h->stats.nif_flops_per_sample = h->env_const ? 0 : h->nif_flops;
+  const uint32_t n = h->n_items;
+  if (n == 0) return PT_OK;
+  PT_HIP(hipMemsetAsync(h->d_counters, 0, 2 * sizeof(unsigned long long), h->stream));
+
+  ptd::TraceParams P;
+  fill_trace_params(h, P);
+  P.n_items = n;
+  size_t ev = 0;
+  hipEvent_t e_begin = get_event(h, ev++);
+  PT_HIP(hipEventRecord(e_begin, h->stream));
+  struct Span { size_t a, b; int kind; };
+  std::vector<Span> spans;
+  uint32_t done = 0;
+  while (done < h->samples_per_step) {
+    const uint32_t iters = std::min(h->iters_per_batch, h->samples_per_step - done);
+    const uint32_t total = iters * n;
+    const TraceGrid g = trace_grid(total);
+    P.sample_base = h->sample_cursor + done;
+    P.total_paths = total;
+    P.n_waves = g.n_waves;
+    P.region_cap = g.region_cap;
+
+    hipEvent_t e0 = get_event(h, ev), e1 = get_event(h, ev + 1), e2 = get_event(h, ev + 2), e3 = get_event(h, ev + 3);
+    PT_HIP(hipEventRecord(e0, h->stream));
+    hipLaunchKernelGGL(ptd::trace_kernel, dim3(g.blocks), dim3(ptd::kTraceBlock), 0, h->stream, P);
+    PT_HIP(hipEventRecord(e1, h->stream));
+    spans.push_back({ev, ev + 1, 0});
+    if (!h->env_const) {
+      ptd::NifParams N = h->nif;
+      N.q_u = h->q_u; N.q_v = h->q_v; N.q_tr = h->q_tr; N.q_tg = h->q_tg; N.q_tb = h->q_tb; N.q_path = h->q_path;
+      N.region_count = h->region_count;
+      N.n_regions = g.blocks;
+      N.region_cap = g.region_cap;
+      N.rad_r = h->rad_r; N.rad_g = h->rad_g; N.rad_b = h->rad_b;
+      N.out_bgr = nullptr;
+      int rc = launch_nif(h, N, h->n_cus);
+      if (rc) return rc;
+      spans.push_back({ev + 1, ev + 2, 1});
+      h->stats.nif_launches += 1;
+    }
+    PT_HIP(hipEventRecord(e2, h->stream));
+    hipLaunchKernelGGL(ptd::accumulate_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, n, iters, h->plen, h->rad_r,
+                       h->rad_g, h->rad_b, h->acc, h->d_counters);
+    PT_HIP(hipEventRecord(e3, h->stream));
+    spans.push_back({ev + 2, ev + 3, 2});
+    ev += 4;
+    h->stats.trace_launches += 1;
+    h->stats.accumulate_launches += 1;
+    done += iters;
+  }
+  hipEvent_t e_end = get_event(h, ev++);
+  PT_HIP(hipEventRecord(e_end, h->stream));
+  PT_HIP(hipGetLastError());
+  PT_HIP(hipStreamSynchronize(h->stream));
+  h->sample_cursor += h->samples_per_step;
+
+  unsigned long long counters[2] = {0, 0};
+  PT_HIP(hipMemcpy(counters, h->d_counters, sizeof(counters), hipMemcpyDeviceToHost));
+  h->stats.paths = (uint64_t)n * h->samples_per_step;
+  h->stats.segments = counters[0];
+  h->stats.escaped = counters[1];
+  for (const Span& s : spans) {
+    float ms = 0.f;
+    PT_HIP(hipEventElapsedTime(&ms, h->events[s.a], h->events[s.b]));
+    if (s.kind == 0) h->stats.path_trace_ms += ms;
+    else if (s.kind == 1) h->stats.nif_ms += ms;
+    else h->stats.accumulate_ms += ms;
+  }
+  float total_ms = 0.f;
+  PT_HIP(hipEventElapsedTime(&total_ms, e_begin, e_end));
+  h->stats.total_ms = total_ms;
+  return PT_OK;
+}
+
+int pt_get_stats(pt_handle h, pt_stats* stats) {
+  if (!h) return PT_ERR_INVALID_ARGUMENT;
+  if (!stats) return fail(h, PT_ERR_INVALID_ARGUMENT, "null stats");
+  *stats = h->stats;
+  return PT_OK;
+}
+
+int pt_read_results(pt_handle h, pt_trace_record* work, size_t n, pt_stats* stats) {
+  if (!h) return PT_ERR_INVALID_ARGUMENT;
+  if (!work && n) return fail(h, PT_ERR_INVALID_ARGUMENT, "null worklist");
+  if (n != h->n_items) return fail(h, PT_ERR_INVALID_ARGUMENT, "worklist size differs from the one given to pt_setup");
+  PT_HIP(hipSetDevice(h->cfg.device));
+  if (n) {
+    hipLaunchKernelGGL(ptd::pack_records_kernel, dim3(((uint32_t)n + 255) / 256), dim3(256), 0, h->stream, h->d_records,
+                       (uint32_t)n, h->acc);
+    PT_HIP(hipGetLastError());
+    PT_HIP(hipMemcpyAsync(work, h->d_records, n * sizeof(pt_trace_record), hipMemcpyDeviceToHost, h->stream));
+    PT_HIP(hipStreamSynchronize(h->stream));
+  }
+  if (stats) *stats = h->stats;
+  return PT_OK;
+}
+
+int pt_export_hdr_device(pt_handle h, void* device_bgr, size_t n) {
+  if (!h) return PT_ERR_INVALID_ARGUMENT;
+  if (!device_bgr || n != h->n_items) return fail(h, PT_ERR_INVALID_ARGUMENT, "bad export buffer");
+  PT_HIP(hipSetDevice(h->cfg.device));
+  if (n) hipLaunchKernelGGL(ptd::export_hdr_kernel, dim3(((uint32_t)n + 255) / 256), dim3(256), 0, h->stream, (uint32_t)n, h->acc,
+                            static_cast<float*>(device_bgr));
+  PT_HIP(hipGetLastError());
+  return PT_OK;
+}
+
+int pt_clear_accumulators(pt_handle h) {
+  if (!h) return PT_ERR_INVALID_ARGUMENT;
+  PT_HIP(hipSetDevice(h->cfg.device));
+  if (h->n_items) hipLaunchKernelGGL(ptd::clear_accum_kernel, dim3((h->n_items + 255) / 256), dim3(256), 0, h->stream, h->n_items, h->acc);
+  PT_HIP(hipGetLastError());
+  return PT_OK;
+}
+
+int pt_synchronize(pt_handle h) {
+  if (!h) return PT_ERR_INVALID_ARGUMENT;
+  PT_HIP(hipSetDevice(h->cfg.device));
+  PT_HIP(hipStreamSynchronize(h->stream));
+  return PT_OK;
+}
+
+int pt_nif_infer(pt_handle h, const float* u, const float* v, size_t n, float* bgr) {
+  if (!h) return PT_ERR_INVALID_ARGUMENT;
+  if (!h->nif_valid) return fail(h, PT_ERR_NOT_READY, "pt_upload_nif has not been called");
+  if (n == 0) return PT_OK;
+  if (!u || !v || !bgr) return fail(h, PT_ERR_INVALID_ARGUMENT, "null buffer");
+  if (n >= (1ull << 31)) return fail(h, PT_ERR_INVALID_ARGUMENT, "too many samples");
+  PT_HIP(hipSetDevice(h->cfg.device));
+  const size_t bytes = n * 4 * 2 + n * 12 + 16;
+  int rc = ensure_scratch(h, bytes);
+  if (rc) return rc;
+  float* d_u = static_cast<float*>(h->d_scratch);
+  float* d_v = d_u + n;
+  float* d_out = d_v + n;
+  uint32_t* d_count = reinterpret_cast<uint32_t*>(d_out + 3 * n);
+  const uint32_t cnt = (uint32_t)n;
+  PT_HIP(hipMemcpyAsync(d_u, u, n * 4, hipMemcpyHostToDevice, h->stream));
+  PT_HIP(hipMemcpyAsync(d_v, v, n * 4, hipMemcpyHostToDevice, h->stream));
+  PT_HIP(hipMemcpyAsync(d_count, &cnt, 4, hipMemcpyHostToDevice, h->stream));
+  ptd::NifParams N = h->nif;
+  N.q_u = d_u; N.q_v = d_v;
+  N.q_tr = N.q_tg = N.q_tb = nullptr; N.q_path = nullptr;
+  N.region_count = d_count;
+  N.n_regions = 1;
+  N.region_cap = cnt;
+  N.rad_r = N.rad_g = N.rad_b = nullptr;
+  N.out_bgr = d_out;
+  rc = launch_nif(h, N, h->n_cus);
+  if (rc) return rc;
+  PT_HIP(hipGetLastError());
+  PT_HIP(hipMemcpyAsync(bgr, d_out, n * 12, hipMemcpyDeviceToHost, h->stream));
+  PT_HIP(hipStreamSynchronize(h->stream));
+  return PT_OK;
+}
+
+int pt_trace_paths(pt_handle h, const uint16_t* u, const uint16_t* v, const uint32_t* sample_index, size_t n,
+                   pt_path_record* out) {
+  if (!h) return PT_ERR_INVALID_ARGUMENT;
+  if (!h->settings_valid) return fail(h, PT_ERR_NOT_READY, "pt_set_render_settings has not been called");
+  if (n == 0) return PT_OK;
+  if (!u || !v || !sample_index || !out) return fail(h, PT_ERR_INVALID_ARGUMENT, "null buffer");
+  PT_HIP(hipSetDevice(h->cfg.device));
+  static_assert(sizeof(pt_path_record) == sizeof(ptd::PathRecordOut), "pt_path_record layout");
+  const size_t bytes = n * (2 + 2 + 4) + 16 + n * sizeof(pt_path_record);
+  int rc = ensure_scratch(h, bytes);
+  if (rc) return rc;
+  char* base = static_cast<char*>(h->d_scratch);
+  ptd::PathRecordOut* d_out = reinterpret_cast<ptd::PathRecordOut*>(base);
+  uint32_t* d_s = reinterpret_cast<uint32_t*>(base + n * sizeof(pt_path_record));
+  uint16_t* d_u = reinterpret_cast<uint16_t*>(d_s + n);
+  uint16_t* d_v = d_u + n;
+  PT_HIP(hipMemcpyAsync(d_s, sample_index, n * 4, hipMemcpyHostToDevice, h->stream));
+  PT_HIP(hipMemcpyAsync(d_u, u, n * 2, hipMemcpyHostToDevice, h->stream));
+  PT_HIP(hipMemcpyAsync(d_v, v, n * 2, hipMemcpyHostToDevice, h->stream));
+  ptd::TraceParams P;
+  fill_trace_params(h, P);
+  hipLaunchKernelGGL(ptd::trace_paths_kernel, dim3(((uint32_t)n + 127) / 128), dim3(128), 0, h->stream, P, d_u, d_v, d_s,
+                     (uint32_t)n, d_out);
+  PT_HIP(hipGetLastError());
+  PT_HIP(hipMemcpyAsync(out, d_out, n * sizeof(pt_path_record), hipMemcpyDeviceToHost, h->stream));
+  PT_HIP(hipStreamSynchronize(h->stream));
+  return PT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,222 @@
+"""ctypes binding of include/ptmi.h (libptmi.so) plus a thin Renderer that sequences the calls the
+way PathTracerApp::execute does (reference: src/PathTracerApp.cpp:612-614, :692-694)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .build import library_path
+
+TRACE_DTYPE = np.dtype([("u", "<u2"), ("v", "<u2"), ("r", "<f4"), ("g", "<f4"), ("b", "<f4"),
+                        ("sampleCount", "<u2"), ("pathLength", "<u2")], align=True)
+assert TRACE_DTYPE.itemsize == 20  # src/codelets/TraceRecord.hpp:7-19
+
+PATH_DTYPE = np.dtype([("length", "<u4"), ("escaped", "<u4"), ("dir", "<f4", 3), ("uv", "<f4", 2),
+                       ("throughput", "<f4", 3), ("cam", "<f4", 2)])
+assert PATH_DTYPE.itemsize == 48
+
+AA_NORMAL, AA_UNIFORM, AA_TRUNCATED_NORMAL = 0, 1, 2
+SAMPLES_HALF, SAMPLES_FLOAT = 0, 1
+DTYPE_F16 = 0
+
+EXPORTS = ["pt_abi_version", "pt_create", "pt_destroy", "pt_last_error", "pt_upload_nif", "pt_set_constant_env",
+           "pt_set_render_settings", "pt_setup", "pt_path_trace", "pt_read_results", "pt_get_stats",
+           "pt_export_hdr_device", "pt_clear_accumulators", "pt_synchronize", "pt_nif_infer", "pt_trace_paths"]
+
+
+class PtError(RuntimeError):
+    """Mirrors the std::runtime_error the reference throws (src/ipu_utils.hpp:532-535)."""
+
+    def __init__(self, code, message):
+        super().__init__("ptmi error %d: %s" % (code, message))
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32),
+                ("max_path_length", C.c_uint32), ("roulette_depth", C.c_uint32), ("stop_prob", C.c_float),
+                ("refractive_index", C.c_float), ("aa_noise_type", C.c_int32), ("sample_precision", C.c_int32),
+                ("device", C.c_int32), ("max_work_items", C.c_uint32), ("iterations_per_batch", C.c_uint32),
+                ("stream", C.c_void_p)]
+
+
+class Layer(C.Structure):
+    _fields_ = [("rows", C.c_uint32), ("cols", C.c_uint32), ("kernel", C.c_void_p), ("bias", C.c_void_p),
+                ("dtype", C.c_int32), ("relu", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("paths", C.c_uint64), ("segments", C.c_uint64), ("escaped", C.c_uint64),
+                ("nif_flops_per_sample", C.c_uint64), ("path_trace_ms", C.c_double), ("nif_ms", C.c_double),
+                ("accumulate_ms", C.c_double), ("total_ms", C.c_double), ("trace_launches", C.c_uint32),
+                ("nif_launches", C.c_uint32), ("accumulate_launches", C.c_uint32), ("reserved", C.c_uint32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+_lib = None
+
+
+def load_library():
+    """Load libptmi.so.  Raises if it has not been built: the product path has no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise FileNotFoundError(
+            "%s not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()')" % path)
+    L = C.CDLL(path)
+    L.pt_abi_version.restype = C.c_int
+    L.pt_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
+    L.pt_destroy.argtypes = [C.c_void_p]
+    L.pt_last_error.restype = C.c_char_p
+    L.pt_last_error.argtypes = [C.c_void_p]
+    L.pt_upload_nif.argtypes = [C.c_void_p, C.POINTER(Layer), C.c_uint32, C.c_uint32, C.c_float,
+                                C.POINTER(C.c_float), C.c_int32]
+    L.pt_set_constant_env.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    L.pt_set_render_settings.argtypes = [C.c_void_p, C.c_uint64, C.c_float, C.c_float, C.c_float, C.c_uint32]
+    L.pt_setup.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.pt_path_trace.argtypes = [C.c_void_p]
+    L.pt_read_results.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(Stats)]
+    L.pt_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+    L.pt_export_hdr_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.pt_clear_accumulators.argtypes = [C.c_void_p]
+    L.pt_synchronize.argtypes = [C.c_void_p]
+    L.pt_nif_infer.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.pt_trace_paths.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    _lib = L
+    return L
+
+
+def degrees_to_radians_f32(deg):
+    """PathTracerApp.cpp:574: float fov = deg * (M_PI / 180.f) evaluated in single precision."""
+    return float(np.float32(deg) * np.float32(np.pi / 180.0))
+
+
+def rotation_to_radians_f32(deg):
+    """PathTracerApp.cpp:584: (degrees / 360.f) * (2.0 * M_PI)."""
+    return float(np.float32((np.float32(deg) / np.float32(360.0)) * (2.0 * np.pi)))
+
+
+class Renderer:
+    """One device context (pt_handle).  Methods are named after the reference's Poplar programs."""
+
+    def __init__(self, width, height, max_work_items=None, max_path_length=10, roulette_depth=3, stop_prob=0.3,
+                 refractive_index=1.5, aa_noise_type=AA_NORMAL, sample_precision=SAMPLES_HALF, device=0,
+                 iterations_per_batch=0, stream=None):
+        self._lib = load_library()
+        cfg = Config()
+        cfg.struct_size = C.sizeof(Config)
+        cfg.width, cfg.height = width, height
+        cfg.max_path_length, cfg.roulette_depth = max_path_length, roulette_depth
+        cfg.stop_prob, cfg.refractive_index = stop_prob, refractive_index
+        cfg.aa_noise_type, cfg.sample_precision = aa_noise_type, sample_precision
+        cfg.device = device
+        cfg.max_work_items = max_work_items if max_work_items else width * height
+        cfg.iterations_per_batch = iterations_per_batch
+        cfg.stream = stream
+        self.handle = C.c_void_p()
+        rc = self._lib.pt_create(C.byref(cfg), C.byref(self.handle))
+        if rc:
+            msg = self._lib.pt_last_error(None).decode()
+            self.handle = None
+            raise PtError(rc, msg)
+        self._keep = []
+
+    def _check(self, rc):
+        if rc:
+            raise PtError(rc, self._lib.pt_last_error(self.handle).decode())
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.pt_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        self.close()
+
+    # ---- program "init_nif_weights"
+    def init_nif_weights(self, layers, embedding_dim, max_value, mean_folded, log_tonemap=True):
+        arr = (Layer * len(layers))()
+        keep = []
+        for i, (k, b, relu) in enumerate(layers):
+            k = np.ascontiguousarray(k, dtype=np.float16)
+            keep.append(k)
+            arr[i].rows, arr[i].cols = k.shape
+            arr[i].kernel = k.ctypes.data
+            if b is not None:
+                b = np.ascontiguousarray(b, dtype=np.float16)
+                keep.append(b)
+                arr[i].bias = b.ctypes.data
+            arr[i].dtype = DTYPE_F16
+            arr[i].relu = int(bool(relu))
+        mean = (C.c_float * 3)(*[float(x) for x in mean_folded])
+        self._check(self._lib.pt_upload_nif(self.handle, arr, len(layers), embedding_dim, float(max_value), mean,
+                                            int(log_tonemap)))
+
+    def set_constant_env(self, rgb):
+        v = (C.c_float * 3)(*[float(x) for x in rgb])
+        self._check(self._lib.pt_set_constant_env(self.handle, v))
+
+    # ---- program "init_render_settings"
+    def init_render_settings(self, seed=1, aa_noise_scale=0.3, fov_degrees=90.0, env_rotation_degrees=0.0,
+                             samples_per_step=1):
+        self._check(self._lib.pt_set_render_settings(self.handle, seed, aa_noise_scale,
+                                                     degrees_to_radians_f32(fov_degrees),
+                                                     rotation_to_radians_f32(env_rotation_degrees), samples_per_step))
+
+    # ---- programs "setup" / "path_trace" / "read_results"
+    def setup(self, records):
+        assert records.dtype == TRACE_DTYPE and records.flags.c_contiguous
+        self._check(self._lib.pt_setup(self.handle, records.ctypes.data, records.size))
+
+    def path_trace(self):
+        self._check(self._lib.pt_path_trace(self.handle))
+
+    def read_results(self, records):
+        assert records.dtype == TRACE_DTYPE and records.flags.c_contiguous
+        st = Stats()
+        self._check(self._lib.pt_read_results(self.handle, records.ctypes.data, records.size, C.byref(st)))
+        return st
+
+    def stats(self):
+        st = Stats()
+        self._check(self._lib.pt_get_stats(self.handle, C.byref(st)))
+        return st
+
+    def export_hdr_device(self, device_ptr, n):
+        self._check(self._lib.pt_export_hdr_device(self.handle, C.c_void_p(device_ptr), n))
+
+    def clear_accumulators(self):
+        self._check(self._lib.pt_clear_accumulators(self.handle))
+
+    def synchronize(self):
+        self._check(self._lib.pt_synchronize(self.handle))
+
+    # ---- kernel-level entry points
+    def nif_infer(self, u, v):
+        u = np.ascontiguousarray(u, dtype=np.float32)
+        v = np.ascontiguousarray(v, dtype=np.float32)
+        out = np.empty((u.size, 3), dtype=np.float32)
+        self._check(self._lib.pt_nif_infer(self.handle, u.ctypes.data, v.ctypes.data, u.size, out.ctypes.data))
+        return out
+
+    def trace_paths(self, u, v, sample_index):
+        u = np.ascontiguousarray(u, dtype=np.uint16)
+        v = np.ascontiguousarray(v, dtype=np.uint16)
+        s = np.ascontiguousarray(sample_index, dtype=np.uint32)
+        out = np.zeros(u.size, dtype=PATH_DTYPE)
+        self._check(self._lib.pt_trace_paths(self.handle, u.ctypes.data, v.ctypes.data, s.ctypes.data, u.size,
+                                             out.ctypes.data))
+        return out
+
+
+def worklist(width, height):
+    """createWorkListForImage (src/LoadBalancer.cpp:38-52): one item per pixel, row-major (c, r)."""
+    rec = np.zeros(width * height, dtype=TRACE_DTYPE)
+    rr, cc = np.divmod(np.arange(width * height), width)
+    rec["u"] = cc
+    rec["v"] = rr
+    return rec

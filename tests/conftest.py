@@ -1,0 +1,28 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import pt_oracle
+    pt_oracle.build()
+    pt_oracle.lib()
+    return pt_oracle
+
+
+@pytest.fixture(scope="session")
+def ptmi_lib():
+    """The product library; GPU tests fail loudly if it is missing (no fallback)."""
+    from ipu_path_trace_amd import ptmi
+    ptmi.load_library()
+    return ptmi

@@ -1,0 +1,158 @@
+"""GPU parity tests proper: HIP kernels (through the C-ABI) against the CPU oracle.
+
+Trace stage: BIT-EXACT (integer path structure and every float of the path record / TraceRecord).
+NIF stage: tolerance -- fp16 MFMA accumulation order differs from the oracle's sequential fp32 sum,
+so a hidden activation can round to the neighbouring half.  Stated bound: decoded radiance within
+2e-2 relative of the oracle, median below 2e-3.
+"""
+import numpy as np
+import pytest
+
+from ipu_path_trace_amd import nif_assets
+
+pytestmark = pytest.mark.gpu
+
+NIF_RTOL_MAX = 2e-2
+NIF_RTOL_MEDIAN = 2e-3
+
+
+def _oracle_paths(O, cfg, u, v, s):
+    out = []
+    for a, b, c in zip(u, v, s):
+        out.append(O.trace_path(cfg, int(a), int(b), int(c)))
+    return out
+
+
+@pytest.mark.parametrize("depth,aa,prec,rot", [(4, 0, 0, 0.0), (8, 0, 0, 37.0), (16, 1, 1, 0.0), (10, 2, 0, 300.0)])
+def test_trace_paths_bit_exact(oracle, ptmi_lib, depth, aa, prec, rot):
+    O = oracle
+    W, H = 1104, 1000
+    rng = np.random.default_rng(1234 + depth)
+    n = 6000
+    u = rng.integers(0, W, n).astype(np.uint16)
+    v = rng.integers(0, H, n).astype(np.uint16)
+    # bias half of the pixels towards the spheres/floor where paths are long
+    v[: n // 2] = rng.integers(H // 2, H, n // 2).astype(np.uint16)
+    u[:8] = 65535  # worklist padding coordinates (LoadBalancer.cpp:66-71) are traced like real ones
+    v[:8] = 65535
+    s = rng.integers(0, 100000, n).astype(np.uint32)
+    cfg = O.make_config(width=W, height=H, max_path_length=depth, aa_noise_type=aa, sample_precision=prec, seed=77,
+                        env_rotation_degrees=rot)
+    r = ptmi_lib.Renderer(W, H, max_work_items=1024, max_path_length=depth, aa_noise_type=aa, sample_precision=prec)
+    r.set_constant_env((1, 1, 1))
+    r.init_render_settings(seed=77, env_rotation_degrees=rot, samples_per_step=1)
+    got = r.trace_paths(u, v, s)
+    ref = _oracle_paths(O, cfg, u, v, s)
+    lengths = np.array([p.length for p in ref], dtype=np.uint32)
+    esc = np.array([p.escaped for p in ref], dtype=np.uint32)
+    assert np.array_equal(got["length"], lengths)
+    assert np.array_equal(got["escaped"], esc)
+    for name in ("dir", "uv", "throughput", "cam"):
+        refv = np.array([list(getattr(p, name)) for p in ref], dtype=np.float32)
+        assert np.array_equal(got[name].view(np.uint32), refv.view(np.uint32)), name
+    assert lengths.max() > 3 and esc.sum() > 0 and (esc == 0).sum() > 0
+    r.close()
+
+
+def test_render_constant_sky_bit_exact_config_c1(oracle, ptmi_lib):
+    """BASELINE config C1: 256x256, 16 spp, depth 4, constant sky.  Every TraceRecord field is identical."""
+    O = oracle
+    W = H = 256
+    cfg = O.make_config(width=W, height=H, max_path_length=4, env_rgb=(1.0, 0.9, 0.8), fold=O.FOLD_FORWARD)
+    ref = O.worklist(W, H)
+    st = O.render(cfg, None, ref, 0, 16)
+    r = ptmi_lib.Renderer(W, H, max_path_length=4, iterations_per_batch=5)  # 16 = 5+5+5+1: exercises a ragged last batch
+    r.set_constant_env((1.0, 0.9, 0.8))
+    r.init_render_settings(seed=1, samples_per_step=16)
+    got = ptmi_lib.worklist(W, H)
+    r.setup(got)
+    r.path_trace()
+    gst = r.read_results(got)
+    assert got.tobytes() == ref.tobytes()
+    assert (gst.paths, gst.segments, gst.escaped) == (st.paths, st.segments, st.escaped)
+    # a second step continues the sample sequence (samples 16..31) and keeps accumulating
+    O.render(cfg, None, ref, 16, 16)
+    r.path_trace()
+    r.read_results(got)
+    assert got.tobytes() == ref.tobytes()
+    r.close()
+
+
+def test_render_backward_fold_matches_forward(oracle, ptmi_lib):
+    """GPU (forward throughput) against the reference's backward fold (codelets.cpp:255-292): rounding only."""
+    O = oracle
+    W = H = 128
+    cfg = O.make_config(width=W, height=H, max_path_length=8, fold=O.FOLD_BACKWARD)
+    ref = O.worklist(W, H)
+    O.render(cfg, None, ref, 0, 8)
+    r = ptmi_lib.Renderer(W, H, max_path_length=8)
+    r.set_constant_env((1, 1, 1))
+    r.init_render_settings(samples_per_step=8)
+    got = ptmi_lib.worklist(W, H)
+    r.setup(got)
+    r.path_trace()
+    r.read_results(got)
+    assert np.array_equal(got["pathLength"], ref["pathLength"])
+    for c in "rgb":
+        np.testing.assert_allclose(got[c], ref[c], rtol=2e-6, atol=1e-7)
+    r.close()
+
+
+@pytest.mark.parametrize("hidden,layers", [(64, 2), (128, 4), (320, 6)])
+def test_nif_infer_matches_oracle(oracle, ptmi_lib, hidden, layers):
+    O = oracle
+    L = nif_assets.synthetic_nif(hidden=hidden, layer_count=layers, seed=7 + hidden)
+    meta = nif_assets.URBAN_ALLEY_META
+    mean = nif_assets.folded_mean()
+    onif = O.Nif(L, 12, meta["max"], mean)
+    r = ptmi_lib.Renderer(64, 64)
+    r.init_nif_weights(L, 12, meta["max"], mean)
+    rng = np.random.default_rng(5)
+    for n in (1, 63, 64, 65, 1000, 50001):  # ragged tiles
+        u = rng.random(n, dtype=np.float32)
+        v = rng.random(n, dtype=np.float32)
+        got = r.nif_infer(u, v)
+        ref = onif.infer(u, v)
+        rel = np.abs(got - ref) / np.abs(ref)
+        assert rel.max() < NIF_RTOL_MAX, (n, rel.max())
+        assert np.median(rel) < NIF_RTOL_MEDIAN
+    r.close()
+
+
+def test_render_with_nif_matches_oracle(oracle, ptmi_lib):
+    O = oracle
+    W = H = 96
+    L = nif_assets.synthetic_nif()
+    meta = nif_assets.URBAN_ALLEY_META
+    mean = nif_assets.folded_mean()
+    onif = O.Nif(L, 12, meta["max"], mean)
+    cfg = O.make_config(width=W, height=H, max_path_length=8, env_mode=O.ENV_NIF, env_rotation_degrees=20.0)
+    ref = O.worklist(W, H)
+    st = O.render(cfg, onif, ref, 0, 6)
+    r = ptmi_lib.Renderer(W, H, max_path_length=8, iterations_per_batch=4)
+    r.init_nif_weights(L, 12, meta["max"], mean)
+    r.init_render_settings(env_rotation_degrees=20.0, samples_per_step=6)
+    got = ptmi_lib.worklist(W, H)
+    r.setup(got)
+    r.path_trace()
+    gst = r.read_results(got)
+    assert np.array_equal(got["pathLength"], ref["pathLength"])
+    assert np.array_equal(got["sampleCount"], ref["sampleCount"])
+    assert (gst.paths, gst.segments, gst.escaped) == (st.paths, st.segments, st.escaped)
+    assert gst.nif_flops_per_sample == 1089283
+    for c in "rgb":
+        np.testing.assert_allclose(got[c], ref[c], rtol=NIF_RTOL_MAX, atol=1e-6)
+    r.close()
+
+
+def test_errors_are_reported(ptmi_lib):
+    r = ptmi_lib.Renderer(32, 32)
+    with pytest.raises(ptmi_lib.PtError):
+        r.path_trace()  # no render settings yet
+    r.init_render_settings(samples_per_step=1)
+    with pytest.raises(ptmi_lib.PtError):
+        r.path_trace()  # no environment
+    bad = nif_assets.synthetic_nif(hidden=96, layer_count=2)
+    with pytest.raises(ptmi_lib.PtError):
+        r.init_nif_weights(bad, 12, 1.0, [0, 0, 0])  # hidden size without an MFMA kernel
+    r.close()
