@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mpath-samples/sec @1104x1000, 300 spp/step, depth 8 (BASELINE.json).
+
+One "step" = one `path_trace` program (reference: src/PathTracerApp.cpp:693) over the resident
+worklist: samples-per-step iterations of ray-gen -> path-trace -> NIF -> accumulate.  The metric is
+the reference's own: W*H*spp_step / seconds (src/PathTracerApp.cpp:766-767), in millions.
+
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL).  The image is tile-partitioned
+(ipu_path_trace_amd/partition.py), every rank traces its tiles with no data-path collective, and the
+HDR tiles are gathered to rank 0 once per save interval (here: once, after the last timed step).
+Total work is fixed as N grows -> "scaling": "strong".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense fp16/bf16
+
+
+def cpu_baseline(width, height, depth, layers, meta, mean, target_seconds=12.0):
+    """Time the CPU oracle (a restatement -- upstream external/light is not vendored) on this host's cores,
+    on a bounded pixel subset of the same workload at 1 spp."""
+    from oracle import pt_oracle as O
+    O.build()
+    nif = O.Nif(layers, meta["embedding_dimension"], meta["max"], mean)
+    cfg = O.make_config(width=width, height=height, max_path_length=depth, env_mode=O.ENV_NIF)
+    full = O.worklist(width, height)
+    rng = np.random.default_rng(0)
+    probe = full[rng.choice(full.size, 20000, replace=False)].copy()
+    t = time.perf_counter()
+    O.render(cfg, nif, probe, 0, 1)
+    rate = probe.size / (time.perf_counter() - t)
+    n = int(min(full.size, max(20000, rate * target_seconds)))
+    sample = full[rng.choice(full.size, n, replace=False)].copy()
+    t = time.perf_counter()
+    st = O.render(cfg, nif, sample, 0, 1)
+    dt = time.perf_counter() - t
+    return {"value": st.paths / dt / 1e6, "unit": "Mpath-samples/s", "cores": int(O.lib().orc_max_threads()),
+            "kind": "port", "sample": "%d random pixels of the %dx%d image x 1 spp, depth %d, same synthetic NIF "
+            "(%.1f s of CPU work)" % (n, width, height, depth, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=1104)
+    ap.add_argument("--height", type=int, default=1000)
+    ap.add_argument("--samples-per-step", type=int, default=300)
+    ap.add_argument("--max-path-length", type=int, default=8)
+    ap.add_argument("--hidden", type=int, default=320)
+    ap.add_argument("--layers", type=int, default=6)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from ipu_path_trace_amd import nif_assets, partition, ptmi
+
+    W, H, spp, depth = args.width, args.height, args.samples_per_step, args.max_path_length
+    meta = dict(nif_assets.URBAN_ALLEY_META)
+    mean = nif_assets.folded_mean(meta)
+    layers = nif_assets.synthetic_nif(hidden=args.hidden, layer_count=args.layers,
+                                      embedding_dim=meta["embedding_dimension"])
+
+    work = partition.tile_order_worklist(W, H, rank, world)
+    counts = partition.items_per_rank(W, H, world)
+    stream = torch.cuda.current_stream().cuda_stream
+    r = ptmi.Renderer(W, H, max_work_items=work.size, max_path_length=depth, device=local_rank, stream=stream)
+    r.init_nif_weights(layers, meta["embedding_dimension"], meta["max"], mean)   # program init_nif_weights
+    r.init_render_settings(seed=1, aa_noise_scale=0.3, fov_degrees=90.0, samples_per_step=spp)
+    r.setup(work)                                                                 # inputs resident in HBM
+    hdr = torch.empty((max(counts), 3), dtype=torch.float32, device="cuda")
+    gathered = [torch.empty_like(hdr) for _ in range(world)] if (world > 1 and rank == 0) else None
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        r.path_trace()
+    agg = {"escaped": 0, "segments": 0, "paths": 0, "nif_ms": 0.0, "trace_ms": 0.0, "acc_ms": 0.0, "nif_launches": 0}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        r.path_trace()
+        st = r.stats()
+        agg["escaped"] += st.escaped
+        agg["segments"] += st.segments
+        agg["paths"] += st.paths
+        agg["nif_ms"] += st.nif_ms
+        agg["trace_ms"] += st.path_trace_ms
+        agg["acc_ms"] += st.accumulate_ms
+        agg["nif_launches"] += st.nif_launches
+    # save-interval film hand-off: mean BGR per work item -> RCCL gather of HDR tiles to rank 0
+    r.export_hdr_device(hdr.data_ptr(), work.size)
+    if world > 1:
+        dist.gather(hdr, gathered, dst=0)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        flops = int(st.nif_flops_per_sample)
+        total_samples = W * H * spp * args.steps
+        nif_s = agg["nif_ms"] * 1e-3
+        achieved = agg["escaped"] * flops / nif_s / 1e12 if nif_s > 0 else 0.0
+        out = {
+            "metric": "Mpath-samples/sec @%dx%d, %d spp/step, depth %d" % (W, H, spp, depth),
+            "value": total_samples / elapsed / 1e6,
+            "unit": "Mpath-samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "configs[1]: %dx%d spheres scene, NIF %dx%d fp16 (synthetic weights, urban_alley "
+                                   "metadata), %d spp/step, depth %d" % (W, H, args.layers, args.hidden, spp, depth),
+                       "parallelism": "image tiles 16x16 round-robin over %d GPU(s), one RCCL gather of HDR tiles"
+                                      % world,
+                       "trace_dtype": "f32", "nif_flops_per_sample": flops,
+                       "escaped_fraction": agg["escaped"] / max(agg["paths"], 1),
+                       "segments_per_path": agg["segments"] / max(agg["paths"], 1)},
+            "roofline": {"bound": "mfma", "kernel": "nif_kernel<%d,12,2>" % args.hidden,
+                         "achieved": achieved, "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / MFMA_F16_DENSE_PEAK_TFLOPS,
+                         "avg_launch_ms": agg["nif_ms"] / max(agg["nif_launches"], 1),
+                         "launches": agg["nif_launches"], "traffic": None,
+                         "rank0_stage_ms": {"trace": agg["trace_ms"], "nif": agg["nif_ms"], "accumulate": agg["acc_ms"]}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(W, H, depth, layers, meta, mean)
+        if world > 1:
+            film = partition.assemble_hdr(W, H, world, [g.cpu().numpy() for g in gathered])
+            out["config"]["film_mean"] = float(film.mean())
+        print(json.dumps(out), flush=True)
+    r.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -171,7 +171,7 @@ void fill_trace_params(pt_handle h, ptd::TraceParams& P) {
   const float fov = host_hround(h->fov);        // field_of_view stream is half (PathTracerApp.cpp:591)
   P.width_f = w;
   P.height_f = hgt;
-  P.tx = tanf(fov * 0.5f);                      // light::pixelToRay (INFERRED, see oracle/pt_oracle.c)
+  P.tx = tanf(fov * 0.5f);                      // light::pixelToRay (INFERRED: DESIGN.md, camera model)
   P.ty = (hgt / w) * P.tx;
   P.aa_scale = host_hround(h->aa_scale);        // anti_alias_scale stream is half (:590)
   P.stop_prob = host_hround(c.stop_prob);       // IpuPathTraceJob.cpp:137

@@ -1,0 +1,71 @@
+"""The C-ABI library loads and exports every symbol include/ptmi.h declares (no compute without a GPU)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "ptmi.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pt_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(ptmi_lib):
+    lib = ptmi_lib.load_library()
+    names = _declared_functions()
+    assert len(names) >= 14
+    for n in names:
+        assert hasattr(lib, n), "libptmi.so does not export %s" % n
+    assert sorted(ptmi_lib.EXPORTS) == names
+    assert lib.pt_abi_version() == 1
+
+
+def test_struct_layouts_match_header(ptmi_lib):
+    assert C.sizeof(ptmi_lib.Config) == 56  # 12 x 4 bytes + pointer
+    assert C.sizeof(ptmi_lib.Layer) == 32
+    assert C.sizeof(ptmi_lib.Stats) == 80
+    assert ptmi_lib.TRACE_DTYPE.itemsize == 20 and ptmi_lib.PATH_DTYPE.itemsize == 48
+
+
+def test_create_rejects_bad_config_and_reports_no_device(ptmi_lib):
+    import torch
+    lib = ptmi_lib.load_library()
+    cfg = ptmi_lib.Config()
+    h = C.c_void_p()
+    assert lib.pt_create(C.byref(cfg), C.byref(h)) == -1  # struct_size mismatch
+    assert b"struct_size" in lib.pt_last_error(None)
+    with pytest.raises(ptmi_lib.PtError) as e:
+        ptmi_lib.Renderer(0, 10)
+    assert e.value.code == -1
+    with pytest.raises(ptmi_lib.PtError):
+        ptmi_lib.Renderer(64, 64, roulette_depth=0)  # undefined behaviour in the reference (codelets.cpp:221)
+    with pytest.raises(ptmi_lib.PtError):
+        ptmi_lib.Renderer(64, 64, max_path_length=65)
+    if not torch.cuda.is_available():
+        # the product path fails loudly without a GPU: there is no CPU fallback behind the C-ABI
+        with pytest.raises(ptmi_lib.PtError) as e:
+            ptmi_lib.Renderer(64, 64)
+        assert e.value.code == -2 and "no CPU fallback" in str(e.value)
+
+
+def test_null_handle_calls_fail_cleanly(ptmi_lib):
+    lib = ptmi_lib.load_library()
+    assert lib.pt_path_trace(None) == -1
+    assert lib.pt_destroy(None) == 0
+    assert lib.pt_setup(None, None, 0) == -1
+
+
+def test_product_package_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under ipu_path_trace_amd/ or bench.py's GPU leg may use it."""
+    pkg = os.path.join(ROOT, "ipu_path_trace_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp", ".c")) or f == "Makefile":
+                src = open(os.path.join(d, f), errors="ignore").read()
+                assert "pt_oracle" not in src and "libpt_oracle" not in src, os.path.join(d, f)
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(d, f)
