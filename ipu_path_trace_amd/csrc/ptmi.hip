@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -284,9 +285,26 @@ int pack_nif(pt_handle h, const std::vector<HostLayer>& L, uint32_t E, std::vect
   return PT_OK;
 }
 
+template <int HID, int E, int NB, int WAVES>
+void launch_nif_v2(pt_handle h, const ptd::NifParams& N, int blocks) {
+  using G = ptd::NifV2Geometry<HID, E, WAVES>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ptd::nif_kernel_v2<HID, E, NB, WAVES>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((ptd::nif_kernel_v2<HID, E, NB, WAVES>), dim3(blocks), dim3(64 * WAVES), G::LDS_BYTES, h->stream, N);
+}
+
 template <int HID, int E>
 void launch_nif_t(pt_handle h, const ptd::NifParams& N, int blocks) {
-  hipLaunchKernelGGL((ptd::nif_kernel<HID, E, 2>), dim3(blocks), dim3(256), 0, h->stream, N);
+  // PTMI_NIF_VARIANT is an A/B switch for profiling: 1 = weights straight from L2 (v1),
+  // 2 = LDS ring, 4 waves x 64 samples, default = LDS ring, 8 waves x 32 samples.
+  static const int variant = getenv("PTMI_NIF_VARIANT") ? atoi(getenv("PTMI_NIF_VARIANT")) : 3;
+  if (variant == 1) hipLaunchKernelGGL((ptd::nif_kernel<HID, E, 2>), dim3(blocks), dim3(256), 0, h->stream, N);
+  else if (variant == 2) launch_nif_v2<HID, E, 2, 4>(h, N, blocks);
+  else launch_nif_v2<HID, E, 1, 8>(h, N, blocks);
 }
 
 int launch_nif(pt_handle h, const ptd::NifParams& N, int blocks) {
