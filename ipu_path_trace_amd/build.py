@@ -10,7 +10,8 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17"
 
 
 def library_path():
-    return os.path.join(_PKG, "libptmi.so")
+    # PTMI_LIBRARY selects another in-tree build of the same sources (e.g. the -DPTMI_DIAG_BUILD ablation library)
+    return os.environ.get("PTMI_LIBRARY") or os.path.join(_PKG, "libptmi.so")
 
 
 def _newer(target, sources):

@@ -17,6 +17,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+#include <utility>
+
 namespace ptd {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -559,6 +562,373 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void nif_kernel_v2(const Nif
         }
       }
     }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the run-ahead DMA before the wave ends
+}
+
+// ---------------------------------------------------------------- v3: every layer through the ring
+//
+// As nif_kernel_v2 with NB = 1, but a ring stage carries TPS output tiles (slab = TPS * ksteps
+// pieces), layer 0 streams through the ring too, and R = 3 slots of 48 KiB fill the 160 KiB LDS.
+// Everything that is not an MFMA is issued in the shadow of one: a tile's k-steps run in groups of
+// four MFMAs, and behind each group the wave issues (a) the LDS reads of the group after next,
+// (b) one chunk of the PREVIOUS tile's epilogue (cvt/bias/ReLU on four accumulator registers) and
+// (c) one piece of the weight DMA for the stage after next.  Measured by ablation
+// (profiles/r01_c_nif_ablation.txt): un-overlapped, the epilogue cost 32 % and the DMA issue burst
+// plus barrier 23 % of the kernel.
+template <int V>
+using IC = std::integral_constant<int, V>;
+template <int... I, class F>
+__device__ __forceinline__ void for_each_index(std::integer_sequence<int, I...>, F&& f) {
+  (f(IC<I>{}), ...);
+}
+
+template <int H, int E, int WAVES, int TPS>
+struct NifV3Geometry {
+  static constexpr int KS = H / 16;
+  static constexpr int NT = H / 32;
+  static constexpr int IS = E / 4;
+  static constexpr int R = 3;
+  static constexpr int SLAB_PIECES = ((TPS * (KS + IS) + WAVES - 1) / WAVES) * WAVES;
+  static constexpr int PW = SLAB_PIECES / WAVES;
+  static constexpr int SLOT_BYTES = SLAB_PIECES * 1024;
+  static constexpr int T0 = (SLAB_PIECES / IS) < NT ? (SLAB_PIECES / IS) : NT;   // layer-0 tiles per slab
+  static constexpr int SCAN_BYTES = ((kMaxRegions + 1) * 4 + 511) / 512 * 512;
+  static constexpr int MAX_LAYERS = 8;                                           // bias tiles resident in LDS
+  static constexpr int BIAS_BYTES = (((MAX_LAYERS - 1) * NT + 1) * 64 + 511) / 512 * 512;
+  static constexpr int LDS_BYTES = SCAN_BYTES + BIAS_BYTES + R * SLOT_BYTES;
+  static_assert(NT % TPS == 0, "tiles per stage must divide the tile count");
+  static_assert(LDS_BYTES <= 160 * 1024, "ring does not fit the LDS");
+};
+
+// DIAG (timing-only builds, results invalid): bit 0 = no ring sync / DMA, bit 1 = no LDS reads of A,
+// bit 2 = no epilogue arithmetic, bit 3 = no encode.
+template <int H, int E, int WAVES, int TPS, int DIAG = 0>
+__global__ __launch_bounds__(64 * WAVES, WAVES / 4) void nif_kernel_v3(const NifParams P) {
+  using G = NifV3Geometry<H, E, WAVES, TPS>;
+  constexpr int KS = G::KS, NT = G::NT, IS = G::IS, R = G::R, PW = G::PW, T0 = G::T0;
+  constexpr int TS = 32;
+  constexpr int THREADS = 64 * WAVES;
+  constexpr int GR = 2;                       // MFMAs per group (A double buffer = 4 fragments)
+  constexpr int NG = KS / GR;                 // groups per tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint32_t* tile_start = reinterpret_cast<uint32_t*>(smem);
+  char* bias_lds = smem + G::SCAN_BYTES;
+  char* ring = bias_lds + G::BIAS_BYTES;
+  const uint32_t ring_lds = __builtin_amdgcn_readfirstlane(
+      (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring);
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = lane & 31;
+  const int h = lane >> 5;
+
+  {  // exclusive scan of per-region wave-tile counts (partials live in the not-yet-used ring)
+    uint32_t* partial = reinterpret_cast<uint32_t*>(ring);
+    const uint32_t per = (P.n_regions + THREADS - 1u) / THREADS;
+    uint32_t sum = 0;
+    for (uint32_t i = 0; i < per; ++i) {
+      uint32_t r = threadIdx.x * per + i;
+      if (r < P.n_regions) sum += (P.region_count[r] + TS - 1u) / TS;
+    }
+    partial[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t run = 0;
+      for (int i = 0; i < THREADS; ++i) { uint32_t t = partial[i]; partial[i] = run; run += t; }
+      tile_start[P.n_regions] = run;
+    }
+    __syncthreads();
+    uint32_t run = partial[threadIdx.x];
+    for (uint32_t i = 0; i < per; ++i) {
+      uint32_t r = threadIdx.x * per + i;
+      if (r < P.n_regions) { tile_start[r] = run; run += (P.region_count[r] + TS - 1u) / TS; }
+    }
+    // bias tiles resident in LDS; layers without a bias carry packed zeros (x + 0 = x in fp16)
+    const uint32_t n_btiles = P.bias_base[P.n_layers - 1] + 1u;
+    for (uint32_t i = threadIdx.x; i < n_btiles * 4u; i += THREADS)
+      reinterpret_cast<uint4*>(bias_lds)[i] = P.bpack[i];
+    __syncthreads();
+  }
+  const uint32_t total_tiles = tile_start[P.n_regions];
+  const uint32_t wg_tiles = (total_tiles + WAVES - 1u) / WAVES;
+  if (blockIdx.x >= wg_tiles) return;   // whole workgroup leaves together
+
+  // Slab stream of one pass: layer 0 in groups of T0 tiles, hidden layers in groups of TPS, head alone.
+  const uint32_t n_layers = P.n_layers;
+  uint32_t pf_l = 0, pf_j = 0, pf_q = 0;   // prefetch cursor: layer, first tile of the slab, stage number
+  uint32_t pf_first = 0, pf_cnt = 1, pf_slot = 0, pf_ntile = 0;
+  auto slab_begin = [&]() {
+    const uint32_t ksteps = (pf_l == 0) ? (uint32_t)IS : KS + (((P.concat_mask >> pf_l) & 1u) ? IS : 0);
+    const uint32_t tiles_l = (pf_l + 1 == n_layers) ? 1u : (uint32_t)NT;
+    const uint32_t group = (pf_l == 0) ? (uint32_t)T0 : (uint32_t)TPS;
+    pf_ntile = (tiles_l - pf_j < group) ? tiles_l - pf_j : group;
+    pf_cnt = pf_ntile * ksteps;
+    pf_first = P.piece_base[pf_l] + pf_j * ksteps;
+    pf_slot = ring_lds + (pf_q % R) * G::SLOT_BYTES;
+  };
+  auto slab_piece = [&](int i) {
+    if constexpr (DIAG & 1) return;
+    uint32_t piece = (uint32_t)wave + (uint32_t)WAVES * i;
+    if (piece >= pf_cnt) piece = pf_cnt - 1u;        // uniform load count: re-load the last piece
+    const char* src = reinterpret_cast<const char*>(P.wpack) + ((size_t)(pf_first + piece) * 1024 + lane * 16);
+    glds16(src, pf_slot + piece * 1024u);
+  };
+  auto slab_end = [&]() {
+    const uint32_t tiles_l = (pf_l + 1 == n_layers) ? 1u : (uint32_t)NT;
+    pf_q += 1;
+    pf_j += pf_ntile;
+    if (pf_j == tiles_l) { pf_j = 0; pf_l = (pf_l + 1 == n_layers) ? 0u : pf_l + 1; }
+  };
+#pragma unroll
+  for (int i = 0; i < R - 1; ++i) {
+    slab_begin();
+#pragma unroll
+    for (int k = 0; k < PW; ++k) slab_piece(k);
+    slab_end();
+  }
+  uint32_t q = 0;   // consumer stage
+  int pf_next = PW; // next piece of the slab being prefetched during this stage (PW = none pending)
+
+  // Start of a ring stage: my pieces of this stage's slab have landed (the slab after it may still be in
+  // flight), everyone's have after the barrier, and the slot read two stages ago is free for the next slab.
+  auto stage_sync = [&]() -> const uint4* {
+    if constexpr (!(DIAG & 1)) {
+#pragma unroll
+      for (int k = 0; k < PW; ++k) if (k >= pf_next) slab_piece(k);   // pieces a short stage had no room for
+      if (pf_next != PW + 1) slab_end();
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW * (R - 2)) : "memory");
+      asm volatile("s_barrier" ::: "memory");
+      slab_begin();
+      pf_next = 0;
+    }
+    const uint4* slot = reinterpret_cast<const uint4*>(ring + (q % R) * G::SLOT_BYTES) + lane;
+    q += 1;
+    return slot;
+  };
+  auto dma_slot = [&]() {   // one DMA piece behind a group of MFMAs
+    if constexpr (!(DIAG & 1)) {
+      if (pf_next < PW) { slab_piece(pf_next); pf_next += 1; }
+    }
+  };
+  pf_next = PW + 1;   // the prologue already issued and closed its slabs
+
+  for (uint32_t g = blockIdx.x; g < wg_tiles; g += gridDim.x) {
+    const uint32_t wt = (uint32_t)WAVES * g + wave;
+    const bool tile_valid = wt < total_tiles;
+    uint32_t lo = 0, hi = P.n_regions;
+    const uint32_t wts = tile_valid ? wt : 0u;
+    while (hi - lo > 1u) {
+      uint32_t mid = (lo + hi) >> 1;
+      if (tile_start[mid] <= wts) lo = mid; else hi = mid;
+    }
+    const uint32_t region = lo;
+    const uint32_t local = (wts - tile_start[region]) * TS;
+    const uint32_t count = tile_valid ? P.region_count[region] : 0u;
+    const uint32_t qi = region * P.region_cap + local + c;
+    const bool sample_valid = local + c < count;
+
+    half8 in[IS];
+    {
+      float coord = 0.5f;
+      if (sample_valid) coord = h ? P.q_v[qi] : P.q_u[qi];
+      const float x = (coord - 1.0f) * 2.0f;
+#pragma unroll
+      for (int s = 0; s < IS; ++s) {
+        half8 f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float a = (float)(_Float16)(x * (float)(1u << (4 * s + k)));
+          float sn, cs;
+          if constexpr (DIAG & 8) { sn = a; cs = a + 1.0f; }
+          else fast_sincos(a, sn, cs);
+          f[k] = (_Float16)sn;
+          f[4 + k] = (_Float16)cs;
+        }
+        in[s] = f;
+      }
+    }
+
+    half8 cur[KS], nxt[KS];
+
+    // Epilogue of one tile in four chunks of four accumulator registers: fp32 -> fp16 (RNE, v_cvt_pk),
+    // + bias in fp16 (v_pk_add_f16), ReLU (v_pk_max_f16): NifModel.cpp:314-325.  Branch-free: a linear
+    // layer uses a floor of -65504.  Chunk ch fills 32-bit words 2*(ch&1), 2*(ch&1)+1 of o0 (ch < 2) or o1.
+    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+    struct Pending {
+      f32x16 acc;
+      const char* bias;   // this lane half's 32 bytes of packed bias
+      bool has_bias, relu;
+    };
+    auto epi_begin = [&](Pending& p, const f32x16& acc, uint32_t layer, int j) __attribute__((always_inline)) {
+      p.acc = acc;
+      p.bias = bias_lds + ((size_t)(P.bias_base[layer] + j) * 2 + h) * 32;
+      p.has_bias = (P.bias_mask >> layer) & 1u;
+      p.relu = (P.relu_mask >> layer) & 1u;
+    };
+    auto epi_chunk = [&](const Pending& p, auto chc, half8& o0, half8& o1) __attribute__((always_inline)) {
+      constexpr int ch = decltype(chc)::value;
+      half8& o = (ch < 2) ? o0 : o1;
+      const int e0 = (ch & 1) * 4;
+      if constexpr (DIAG & 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[e0 + i] = (_Float16)1.0f;
+        asm volatile("" ::"v"(p.acc[4 * ch]));
+        return;
+      }
+      // uniform branches on purpose: they split the block, which keeps hipcc's register pressure in budget
+      // (the branch-free form spills ~200 VGPRs), and in-order issue overlaps the chunk with the MFMAs anyway
+      half2v x0 = {(_Float16)p.acc[4 * ch + 0], (_Float16)p.acc[4 * ch + 1]};
+      half2v x1 = {(_Float16)p.acc[4 * ch + 2], (_Float16)p.acc[4 * ch + 3]};
+      if (p.has_bias) {
+        union { uint2 u; half2v hh[2]; } bb;
+        bb.u = *reinterpret_cast<const uint2*>(p.bias + ch * 8);
+        x0 = x0 + bb.hh[0];
+        x1 = x1 + bb.hh[1];
+      }
+      if (p.relu) {
+        const half2v z = {(_Float16)0.0f, (_Float16)0.0f};
+        x0 = __builtin_elementwise_max(x0, z);
+        x1 = __builtin_elementwise_max(x1, z);
+      }
+      o[e0 + 0] = x0[0]; o[e0 + 1] = x0[1];
+      o[e0 + 2] = x1[0]; o[e0 + 3] = x1[1];
+    };
+    auto epi_all = [&](const Pending& p, half8& o0, half8& o1) __attribute__((always_inline)) {
+      epi_chunk(p, IC<0>{}, o0, o1);
+      epi_chunk(p, IC<1>{}, o0, o1);
+      epi_chunk(p, IC<2>{}, o0, o1);
+      epi_chunk(p, IC<3>{}, o0, o1);
+    };
+
+    // One 32-feature output tile.  A fragments come from LDS in groups of GR, two groups in flight; the
+    // empty asm pins that order (hipcc otherwise sinks every ds_read next to its MFMA and waits
+    // lgkmcnt(0) per k-step) and makes the compiler wait for exactly the group about to multiply.
+    auto tile_mma = [&](const uint4* wj, half8 (&src)[KS], bool concat, f32x16& acc, auto&& after_group)
+                        __attribute__((always_inline)) {
+      acc = (f32x16)(0.0f);
+      half8 A[2][GR];
+#pragma unroll
+      for (int i = 0; i < GR; ++i) A[0][i] = (DIAG & 2) ? in[i % IS] : as_half8(wj[i * 64]);
+      auto group = [&](auto gc) __attribute__((always_inline)) {
+        constexpr int g2 = decltype(gc)::value;
+        if constexpr (g2 + 1 < NG) {
+#pragma unroll
+          for (int i = 0; i < GR; ++i)
+            A[(g2 + 1) & 1][i] = (DIAG & 2) ? in[(g2 + i) % IS] : as_half8(wj[((g2 + 1) * GR + i) * 64]);
+        }
+        if constexpr (GR == 4)
+          asm volatile("" : "+v"(A[g2 & 1][0]), "+v"(A[g2 & 1][1]), "+v"(A[g2 & 1][2]), "+v"(A[g2 & 1][3])::"memory");
+        else
+          asm volatile("" : "+v"(A[g2 & 1][0]), "+v"(A[g2 & 1][1])::"memory");
+#pragma unroll
+        for (int i = 0; i < GR; ++i)
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[g2 & 1][i], src[g2 * GR + i], acc, 0, 0, 0);
+        after_group(gc);
+      };
+      for_each_index(std::make_integer_sequence<int, NG>{}, group);
+      if (concat) {
+        half8 t[IS];
+#pragma unroll
+        for (int s = 0; s < IS; ++s) t[s] = as_half8(wj[(KS + s) * 64]);
+#pragma unroll
+        for (int s = 0; s < IS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(t[s], in[s], acc, 0, 0, 0);
+      }
+    };
+
+    // ---- layer 0: 4E -> H, slabs of T0 tiles (3 MFMAs per tile: epilogue and DMA ride behind each tile)
+    {
+      const uint4* slot = nullptr;
+      Pending pend;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        if (j % T0 == 0) slot = stage_sync();
+        half8 a0[IS];
+#pragma unroll
+        for (int s = 0; s < IS; ++s) a0[s] = as_half8(slot[((j % T0) * IS + s) * 64]);
+        f32x16 acc = (f32x16)(0.0f);
+#pragma unroll
+        for (int s = 0; s < IS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[s], in[s], acc, 0, 0, 0);
+        if (j > 0) epi_all(pend, cur[2 * (j - 1)], cur[2 * (j - 1) + 1]);
+        dma_slot();
+        epi_begin(pend, acc, 0, j);
+      }
+      epi_all(pend, cur[2 * (NT - 1)], cur[2 * (NT - 1) + 1]);
+    }
+
+    // ---- hidden layers; src/dst register sets alternate so nothing is copied
+    auto hidden = [&](half8 (&src)[KS], half8 (&dst)[KS], uint32_t l) __attribute__((always_inline)) {
+      const bool concat = (P.concat_mask >> l) & 1u;
+      const uint32_t ksteps = KS + (concat ? IS : 0);
+      Pending pend;
+      const uint4* slot = nullptr;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        if (j % TPS == 0) slot = stage_sync();
+        f32x16 acc;
+        tile_mma(slot + (size_t)(j % TPS) * ksteps * 64, src, concat, acc, [&](auto gc) __attribute__((always_inline)) {
+          constexpr int g2 = decltype(gc)::value;
+          if constexpr (g2 < 4) { if (j > 0) epi_chunk(pend, gc, dst[2 * (j - 1)], dst[2 * (j - 1) + 1]); }
+          dma_slot();
+        });
+        if (j > 0) {
+          if constexpr (NG < 2) epi_chunk(pend, IC<1>{}, dst[2 * (j - 1)], dst[2 * (j - 1) + 1]);
+          if constexpr (NG < 3) epi_chunk(pend, IC<2>{}, dst[2 * (j - 1)], dst[2 * (j - 1) + 1]);
+          if constexpr (NG < 4) epi_chunk(pend, IC<3>{}, dst[2 * (j - 1)], dst[2 * (j - 1) + 1]);
+        }
+        epi_begin(pend, acc, l, j);
+      }
+      epi_all(pend, dst[2 * (NT - 1)], dst[2 * (NT - 1) + 1]);
+    };
+    {
+      uint32_t l = 1;
+      for (; l + 2 < n_layers; l += 2) {
+        hidden(cur, nxt, l);
+        hidden(nxt, cur, l + 1);
+      }
+      if (l + 1 < n_layers) {  // odd number of hidden layers behind layer 0
+        hidden(cur, nxt, l);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) cur[s] = nxt[s];
+      }
+    }
+
+    // ---- head
+    {
+      const uint32_t l = n_layers - 1;
+      const bool concat = (P.concat_mask >> l) & 1u;
+      const uint4* slot = stage_sync();
+      f32x16 acc;
+      tile_mma(slot, cur, concat, acc, [&](auto) __attribute__((always_inline)) { dma_slot(); });
+      Pending pend;
+      epi_begin(pend, acc, l, 0);
+      half8 o0, o1;
+      epi_chunk(pend, IC<0>{}, o0, o1);
+      if (h == 0 && sample_valid) {
+        float bgr[3];
+        const float mean[3] = {P.mean0, P.mean1, P.mean2};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          float o = (float)o0[k] * P.max;
+          o = o + mean[k];
+          bgr[k] = P.log_tonemap ? __expf(o) : o;
+        }
+        if (P.out_bgr) {
+          P.out_bgr[3 * (size_t)qi + 0] = bgr[0];
+          P.out_bgr[3 * (size_t)qi + 1] = bgr[1];
+          P.out_bgr[3 * (size_t)qi + 2] = bgr[2];
+        } else {
+          const uint32_t path = P.q_path[qi];
+          P.rad_r[path] = bgr[2] * P.q_tr[qi];
+          P.rad_g[path] = bgr[1] * P.q_tg[qi];
+          P.rad_b[path] = bgr[0] * P.q_tb[qi];
+        }
+      }
+    }
+  }
+  if constexpr (!(DIAG & 1)) {
+#pragma unroll
+    for (int k = 0; k < PW; ++k) if (k >= pf_next) slab_piece(k);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the run-ahead DMA before the wave ends
 }

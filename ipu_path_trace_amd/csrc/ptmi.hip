@@ -297,14 +297,51 @@ void launch_nif_v2(pt_handle h, const ptd::NifParams& N, int blocks) {
   hipLaunchKernelGGL((ptd::nif_kernel_v2<HID, E, NB, WAVES>), dim3(blocks), dim3(64 * WAVES), G::LDS_BYTES, h->stream, N);
 }
 
+template <int HID, int E, int WAVES, int TPS, int DIAG = 0>
+void launch_nif_v3(pt_handle h, const ptd::NifParams& N, int blocks) {
+  using G = ptd::NifV3Geometry<HID, E, WAVES, TPS>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ptd::nif_kernel_v3<HID, E, WAVES, TPS, DIAG>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((ptd::nif_kernel_v3<HID, E, WAVES, TPS, DIAG>), dim3(blocks), dim3(64 * WAVES), G::LDS_BYTES, h->stream, N);
+}
+
+#ifdef PTMI_DIAG_BUILD
+// Timing-only ablations of the headline kernel (results are garbage): see nif_kernel_v3's DIAG bits.
+template <int HID, int E>
+bool launch_nif_diag(pt_handle h, const ptd::NifParams& N, int blocks) {
+  static const int diag = getenv("PTMI_NIF_DIAG") ? atoi(getenv("PTMI_NIF_DIAG")) : 0;
+  if constexpr (HID == 320 && E == 12) {
+    switch (diag) {
+      case 1: launch_nif_v3<HID, E, 8, 2, 1>(h, N, blocks); return true;
+      case 2: launch_nif_v3<HID, E, 8, 2, 2>(h, N, blocks); return true;
+      case 3: launch_nif_v3<HID, E, 8, 2, 3>(h, N, blocks); return true;
+      case 4: launch_nif_v3<HID, E, 8, 2, 4>(h, N, blocks); return true;
+      case 7: launch_nif_v3<HID, E, 8, 2, 7>(h, N, blocks); return true;
+      case 15: launch_nif_v3<HID, E, 8, 2, 15>(h, N, blocks); return true;
+      default: break;
+    }
+  }
+  return false;
+}
+#endif
+
 template <int HID, int E>
 void launch_nif_t(pt_handle h, const ptd::NifParams& N, int blocks) {
   // PTMI_NIF_VARIANT is an A/B switch for profiling: 1 = weights straight from L2 (v1),
-  // 2 = LDS ring, 4 waves x 64 samples, default = LDS ring, 8 waves x 32 samples.
-  static const int variant = getenv("PTMI_NIF_VARIANT") ? atoi(getenv("PTMI_NIF_VARIANT")) : 3;
+  // 2 = LDS ring, 4 waves x 64 samples, 3 = LDS ring, 8 waves x 32 samples, one tile per stage,
+  // default (4) = all layers through the ring, two tiles per stage.
+  static const int variant = getenv("PTMI_NIF_VARIANT") ? atoi(getenv("PTMI_NIF_VARIANT")) : 4;
+#ifdef PTMI_DIAG_BUILD
+  if (launch_nif_diag<HID, E>(h, N, blocks)) return;
+#endif
   if (variant == 1) hipLaunchKernelGGL((ptd::nif_kernel<HID, E, 2>), dim3(blocks), dim3(256), 0, h->stream, N);
   else if (variant == 2) launch_nif_v2<HID, E, 2, 4>(h, N, blocks);
-  else launch_nif_v2<HID, E, 1, 8>(h, N, blocks);
+  else if (variant == 3 || N.n_layers > (uint32_t)ptd::NifV3Geometry<HID, E, 8, 2>::MAX_LAYERS) launch_nif_v2<HID, E, 1, 8>(h, N, blocks);
+  else launch_nif_v3<HID, E, 8, 2>(h, N, blocks);
 }
 
 int launch_nif(pt_handle h, const ptd::NifParams& N, int blocks) {
