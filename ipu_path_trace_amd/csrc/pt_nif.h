@@ -758,15 +758,14 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void nif_kernel_v3(const Nif
     struct Pending {
       f32x16 acc;
       const char* bias;   // this lane half's 32 bytes of packed bias
-      bool has_bias, relu;
+      uint32_t floor;     // packed fp16 pair: 0 (ReLU) or -inf (linear)
     };
     auto epi_begin = [&](Pending& p, const f32x16& acc, uint32_t layer, int j) __attribute__((always_inline)) {
       p.acc = acc;
       p.bias = bias_lds + ((size_t)(P.bias_base[layer] + j) * 2 + h) * 32;
-      p.has_bias = (P.bias_mask >> layer) & 1u;
-      p.relu = (P.relu_mask >> layer) & 1u;
+      p.floor = ((P.relu_mask >> layer) & 1u) ? 0u : 0xfc00fc00u;
     };
-    auto epi_chunk = [&](const Pending& p, auto chc, half8& o0, half8& o1) __attribute__((always_inline)) {
+    auto epi_chunk = [&](const Pending& p, auto chc, half8& o0, half8& o1, uint2 bias_now) __attribute__((always_inline)) {
       constexpr int ch = decltype(chc)::value;
       half8& o = (ch < 2) ? o0 : o1;
       const int e0 = (ch & 1) * 4;
@@ -780,25 +779,25 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void nif_kernel_v3(const Nif
       // (the branch-free form spills ~200 VGPRs), and in-order issue overlaps the chunk with the MFMAs anyway
       half2v x0 = {(_Float16)p.acc[4 * ch + 0], (_Float16)p.acc[4 * ch + 1]};
       half2v x1 = {(_Float16)p.acc[4 * ch + 2], (_Float16)p.acc[4 * ch + 3]};
-      if (p.has_bias) {
-        union { uint2 u; half2v hh[2]; } bb;
-        bb.u = *reinterpret_cast<const uint2*>(p.bias + ch * 8);
+      {
+        union { uint2 u; half2v hh[2]; } bb;   // layers without a bias carry packed zeros: x + 0 = x
+        bb.u = bias_now;
         x0 = x0 + bb.hh[0];
         x1 = x1 + bb.hh[1];
       }
-      if (p.relu) {
-        const half2v z = {(_Float16)0.0f, (_Float16)0.0f};
-        x0 = __builtin_elementwise_max(x0, z);
-        x1 = __builtin_elementwise_max(x1, z);
-      }
+      // ReLU as one v_pk_max_f16 against a uniform floor (0, or -inf for a linear layer: max(x, -inf) = x);
+      // the builtin max costs a canonicalising max and a select on top
+      asm("v_pk_max_f16 %0, %1, %2" : "=v"(x0) : "v"(x0), "s"(p.floor));
+      asm("v_pk_max_f16 %0, %1, %2" : "=v"(x1) : "v"(x1), "s"(p.floor));
       o[e0 + 0] = x0[0]; o[e0 + 1] = x0[1];
       o[e0 + 2] = x1[0]; o[e0 + 3] = x1[1];
     };
+    auto bias_at = [&](const Pending& p, int ch) -> uint2 { return *reinterpret_cast<const uint2*>(p.bias + ch * 8); };
     auto epi_all = [&](const Pending& p, half8& o0, half8& o1) __attribute__((always_inline)) {
-      epi_chunk(p, IC<0>{}, o0, o1);
-      epi_chunk(p, IC<1>{}, o0, o1);
-      epi_chunk(p, IC<2>{}, o0, o1);
-      epi_chunk(p, IC<3>{}, o0, o1);
+      epi_chunk(p, IC<0>{}, o0, o1, bias_at(p, 0));
+      epi_chunk(p, IC<1>{}, o0, o1, bias_at(p, 1));
+      epi_chunk(p, IC<2>{}, o0, o1, bias_at(p, 2));
+      epi_chunk(p, IC<3>{}, o0, o1, bias_at(p, 3));
     };
 
     // One 32-feature output tile.  A fragments come from LDS in groups of GR, two groups in flight; the
@@ -861,6 +860,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void nif_kernel_v3(const Nif
       const bool concat = (P.concat_mask >> l) & 1u;
       const uint32_t ksteps = KS + (concat ? IS : 0);
       Pending pend;
+      uint2 b_next = {0u, 0u};
       const uint4* slot = nullptr;
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
@@ -868,15 +868,22 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void nif_kernel_v3(const Nif
         f32x16 acc;
         tile_mma(slot + (size_t)(j % TPS) * ksteps * 64, src, concat, acc, [&](auto gc) __attribute__((always_inline)) {
           constexpr int g2 = decltype(gc)::value;
-          if constexpr (g2 < 4) { if (j > 0) epi_chunk(pend, gc, dst[2 * (j - 1)], dst[2 * (j - 1) + 1]); }
+          if constexpr (g2 < 4) {
+            if (j > 0) {
+              const uint2 b_now = b_next;
+              if constexpr (g2 < 3 && g2 + 1 < NG) b_next = bias_at(pend, g2 + 1);   // lands behind the next group's MFMAs
+              epi_chunk(pend, gc, dst[2 * (j - 1)], dst[2 * (j - 1) + 1], b_now);
+            }
+          }
           dma_slot();
         });
-        if (j > 0) {
-          if constexpr (NG < 2) epi_chunk(pend, IC<1>{}, dst[2 * (j - 1)], dst[2 * (j - 1) + 1]);
-          if constexpr (NG < 3) epi_chunk(pend, IC<2>{}, dst[2 * (j - 1)], dst[2 * (j - 1) + 1]);
-          if constexpr (NG < 4) epi_chunk(pend, IC<3>{}, dst[2 * (j - 1)], dst[2 * (j - 1) + 1]);
+        if (j > 0) {   // narrow networks: fewer than four groups per tile, finish the leftover chunks here
+          if constexpr (NG < 2) epi_chunk(pend, IC<1>{}, dst[2 * (j - 1)], dst[2 * (j - 1) + 1], bias_at(pend, 1));
+          if constexpr (NG < 3) epi_chunk(pend, IC<2>{}, dst[2 * (j - 1)], dst[2 * (j - 1) + 1], bias_at(pend, 2));
+          if constexpr (NG < 4) epi_chunk(pend, IC<3>{}, dst[2 * (j - 1)], dst[2 * (j - 1) + 1], bias_at(pend, 3));
         }
         epi_begin(pend, acc, l, j);
+        b_next = bias_at(pend, 0);   // read one tile ahead of chunk 0
       }
       epi_all(pend, dst[2 * (NT - 1)], dst[2 * (NT - 1) + 1]);
     };
@@ -903,7 +910,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void nif_kernel_v3(const Nif
       Pending pend;
       epi_begin(pend, acc, l, 0);
       half8 o0, o1;
-      epi_chunk(pend, IC<0>{}, o0, o1);
+      epi_chunk(pend, IC<0>{}, o0, o1, bias_at(pend, 0));
       if (h == 0 && sample_valid) {
         float bgr[3];
         const float mean[3] = {P.mean0, P.mean1, P.mean2};
