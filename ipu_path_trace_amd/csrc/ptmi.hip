@@ -73,15 +73,21 @@ struct pt_context {
   ptd::Accum acc{};
   unsigned long long* d_counters = nullptr;  // [0] segments, [1] escaped
 
-  // batch buffers
+  // batch buffers, double-buffered: the trace kernel of batch b+1 runs on `trace_stream` while the NIF
+  // kernel of batch b (MFMA-bound) runs on `stream`
   uint32_t iters_per_batch = 1;
   size_t batch_paths_cap = 0;
-  float *q_u = nullptr, *q_v = nullptr, *q_tr = nullptr, *q_tg = nullptr, *q_tb = nullptr;
-  uint32_t* q_path = nullptr;
   size_t queue_cap = 0;
-  uint32_t* region_count = nullptr;
-  uint8_t* plen = nullptr;
-  float *rad_r = nullptr, *rad_g = nullptr, *rad_b = nullptr;
+  struct BatchBuffers {
+    float *q_u = nullptr, *q_v = nullptr, *q_tr = nullptr, *q_tg = nullptr, *q_tb = nullptr;
+    uint32_t* q_path = nullptr;
+    uint32_t* region_count = nullptr;
+    uint8_t* plen = nullptr;
+    float *rad_r = nullptr, *rad_g = nullptr, *rad_b = nullptr;
+    hipEvent_t traced = nullptr;       // trace kernel of the batch using this set has finished
+    hipEvent_t accumulated = nullptr;  // accumulate kernel has consumed this set
+  } bb[2];
+  hipStream_t trace_stream = nullptr;
 
   // render settings
   bool settings_valid = false;
@@ -188,10 +194,13 @@ void fill_trace_params(pt_handle h, ptd::TraceParams& P) {
   P.env_const = h->env_const ? 1 : 0;
   P.env_r = h->env_rgb[0]; P.env_g = h->env_rgb[1]; P.env_b = h->env_rgb[2];
   P.pix = h->acc.pix;
-  P.q_u = h->q_u; P.q_v = h->q_v; P.q_tr = h->q_tr; P.q_tg = h->q_tg; P.q_tb = h->q_tb; P.q_path = h->q_path;
-  P.region_count = h->region_count;
-  P.plen = h->plen;
-  P.rad_r = h->rad_r; P.rad_g = h->rad_g; P.rad_b = h->rad_b;
+}
+
+void bind_batch(ptd::TraceParams& P, const pt_context::BatchBuffers& B) {
+  P.q_u = B.q_u; P.q_v = B.q_v; P.q_tr = B.q_tr; P.q_tg = B.q_tg; P.q_tb = B.q_tb; P.q_path = B.q_path;
+  P.region_count = B.region_count;
+  P.plen = B.plen;
+  P.rad_r = B.rad_r; P.rad_g = B.rad_g; P.rad_b = B.rad_b;
 }
 
 // Trace-grid geometry for a batch of `total` paths.
@@ -365,10 +374,14 @@ bool nif_shape_supported(uint32_t hidden, uint32_t emb) {
 }
 
 void free_batch_buffers(pt_handle h) {
-  (void)hipFree(h->q_u); (void)hipFree(h->q_v); (void)hipFree(h->q_tr); (void)hipFree(h->q_tg); (void)hipFree(h->q_tb); (void)hipFree(h->q_path);
-  (void)hipFree(h->region_count); (void)hipFree(h->plen); (void)hipFree(h->rad_r); (void)hipFree(h->rad_g); (void)hipFree(h->rad_b);
-  h->q_u = h->q_v = h->q_tr = h->q_tg = h->q_tb = nullptr; h->q_path = nullptr;
-  h->region_count = nullptr; h->plen = nullptr; h->rad_r = h->rad_g = h->rad_b = nullptr;
+  for (auto& B : h->bb) {
+    (void)hipFree(B.q_u); (void)hipFree(B.q_v); (void)hipFree(B.q_tr); (void)hipFree(B.q_tg); (void)hipFree(B.q_tb);
+    (void)hipFree(B.q_path); (void)hipFree(B.region_count); (void)hipFree(B.plen);
+    (void)hipFree(B.rad_r); (void)hipFree(B.rad_g); (void)hipFree(B.rad_b);
+    if (B.traced) (void)hipEventDestroy(B.traced);
+    if (B.accumulated) (void)hipEventDestroy(B.accumulated);
+    B = pt_context::BatchBuffers();
+  }
 }
 
 hipEvent_t get_event(pt_handle h, size_t i) {
@@ -439,17 +452,22 @@ int pt_create(const pt_config* cfg, pt_handle* out) {
   PT_HIPC(dev_alloc(&h->d_counters, 2));
   const TraceGrid g = trace_grid((uint32_t)h->batch_paths_cap);
   h->queue_cap = (size_t)g.blocks * g.region_cap;
-  PT_HIPC(dev_alloc(&h->q_u, h->queue_cap));
-  PT_HIPC(dev_alloc(&h->q_v, h->queue_cap));
-  PT_HIPC(dev_alloc(&h->q_tr, h->queue_cap));
-  PT_HIPC(dev_alloc(&h->q_tg, h->queue_cap));
-  PT_HIPC(dev_alloc(&h->q_tb, h->queue_cap));
-  PT_HIPC(dev_alloc(&h->q_path, h->queue_cap));
-  PT_HIPC(dev_alloc(&h->region_count, (size_t)ptd::kMaxRegions));
-  PT_HIPC(dev_alloc(&h->plen, h->batch_paths_cap));
-  PT_HIPC(dev_alloc(&h->rad_r, h->batch_paths_cap));
-  PT_HIPC(dev_alloc(&h->rad_g, h->batch_paths_cap));
-  PT_HIPC(dev_alloc(&h->rad_b, h->batch_paths_cap));
+  for (auto& B : h->bb) {
+    PT_HIPC(dev_alloc(&B.q_u, h->queue_cap));
+    PT_HIPC(dev_alloc(&B.q_v, h->queue_cap));
+    PT_HIPC(dev_alloc(&B.q_tr, h->queue_cap));
+    PT_HIPC(dev_alloc(&B.q_tg, h->queue_cap));
+    PT_HIPC(dev_alloc(&B.q_tb, h->queue_cap));
+    PT_HIPC(dev_alloc(&B.q_path, h->queue_cap));
+    PT_HIPC(dev_alloc(&B.region_count, (size_t)ptd::kMaxRegions));
+    PT_HIPC(dev_alloc(&B.plen, h->batch_paths_cap));
+    PT_HIPC(dev_alloc(&B.rad_r, h->batch_paths_cap));
+    PT_HIPC(dev_alloc(&B.rad_g, h->batch_paths_cap));
+    PT_HIPC(dev_alloc(&B.rad_b, h->batch_paths_cap));
+    PT_HIPC(hipEventCreateWithFlags(&B.traced, hipEventDisableTiming));
+    PT_HIPC(hipEventCreateWithFlags(&B.accumulated, hipEventDisableTiming));
+  }
+  PT_HIPC(hipStreamCreateWithFlags(&h->trace_stream, hipStreamNonBlocking));
 #undef PT_HIPC
   *out = h;
   return PT_OK;
@@ -465,6 +483,7 @@ int pt_destroy(pt_handle h) {
   (void)hipFree(h->d_wpack); (void)hipFree(h->d_bpack);
   (void)hipFree(h->d_scratch);
   for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
+  if (h->trace_stream) { (void)hipStreamSynchronize(h->trace_stream); (void)hipStreamDestroy(h->trace_stream); }
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return PT_OK;
@@ -569,53 +588,66 @@ int pt_path_trace(pt_handle h) {
   ptd::TraceParams P;
   fill_trace_params(h, P);
   P.n_items = n;
+  // Schedule: T(b) on trace_stream; N(b) and A(b) on stream.  T(b+1) overlaps N(b) (VALU under MFMA);
+  // buffer set b&1 is reused by T(b+2) once A(b) has consumed it.
   size_t ev = 0;
   hipEvent_t e_begin = get_event(h, ev++);
   PT_HIP(hipEventRecord(e_begin, h->stream));
+  PT_HIP(hipStreamWaitEvent(h->trace_stream, e_begin, 0));   // counters memset and earlier work on `stream`
   struct Span { size_t a, b; int kind; };
   std::vector<Span> spans;
-  uint32_t done = 0;
+  uint32_t done = 0, batch = 0;
   while (done < h->samples_per_step) {
     const uint32_t iters = std::min(h->iters_per_batch, h->samples_per_step - done);
     const uint32_t total = iters * n;
     const TraceGrid g = trace_grid(total);
+    pt_context::BatchBuffers& B = h->bb[batch & 1];
     P.sample_base = h->sample_cursor + done;
     P.total_paths = total;
     P.n_waves = g.n_waves;
     P.region_cap = g.region_cap;
+    bind_batch(P, B);
 
-    hipEvent_t e0 = get_event(h, ev), e1 = get_event(h, ev + 1), e2 = get_event(h, ev + 2), e3 = get_event(h, ev + 3);
-    PT_HIP(hipEventRecord(e0, h->stream));
-    hipLaunchKernelGGL(ptd::trace_kernel, dim3(g.blocks), dim3(ptd::kTraceBlock), 0, h->stream, P);
-    PT_HIP(hipEventRecord(e1, h->stream));
+    hipEvent_t t0 = get_event(h, ev), t1 = get_event(h, ev + 1), n0 = get_event(h, ev + 2), n1 = get_event(h, ev + 3),
+               a1 = get_event(h, ev + 4);
+    if (batch >= 2) PT_HIP(hipStreamWaitEvent(h->trace_stream, B.accumulated, 0));
+    PT_HIP(hipEventRecord(t0, h->trace_stream));
+    hipLaunchKernelGGL(ptd::trace_kernel, dim3(g.blocks), dim3(ptd::kTraceBlock), 0, h->trace_stream, P);
+    PT_HIP(hipEventRecord(t1, h->trace_stream));
+    PT_HIP(hipEventRecord(B.traced, h->trace_stream));
     spans.push_back({ev, ev + 1, 0});
+    PT_HIP(hipStreamWaitEvent(h->stream, B.traced, 0));
+    PT_HIP(hipEventRecord(n0, h->stream));
     if (!h->env_const) {
       ptd::NifParams N = h->nif;
-      N.q_u = h->q_u; N.q_v = h->q_v; N.q_tr = h->q_tr; N.q_tg = h->q_tg; N.q_tb = h->q_tb; N.q_path = h->q_path;
-      N.region_count = h->region_count;
+      N.q_u = B.q_u; N.q_v = B.q_v; N.q_tr = B.q_tr; N.q_tg = B.q_tg; N.q_tb = B.q_tb; N.q_path = B.q_path;
+      N.region_count = B.region_count;
       N.n_regions = g.blocks;
       N.region_cap = g.region_cap;
-      N.rad_r = h->rad_r; N.rad_g = h->rad_g; N.rad_b = h->rad_b;
+      N.rad_r = B.rad_r; N.rad_g = B.rad_g; N.rad_b = B.rad_b;
       N.out_bgr = nullptr;
       int rc = launch_nif(h, N, h->n_cus);
       if (rc) return rc;
-      spans.push_back({ev + 1, ev + 2, 1});
+      spans.push_back({ev + 2, ev + 3, 1});
       h->stats.nif_launches += 1;
     }
-    PT_HIP(hipEventRecord(e2, h->stream));
-    hipLaunchKernelGGL(ptd::accumulate_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, n, iters, h->plen, h->rad_r,
-                       h->rad_g, h->rad_b, h->acc, h->d_counters);
-    PT_HIP(hipEventRecord(e3, h->stream));
-    spans.push_back({ev + 2, ev + 3, 2});
-    ev += 4;
+    PT_HIP(hipEventRecord(n1, h->stream));
+    hipLaunchKernelGGL(ptd::accumulate_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, n, iters, B.plen, B.rad_r,
+                       B.rad_g, B.rad_b, h->acc, h->d_counters);
+    PT_HIP(hipEventRecord(a1, h->stream));
+    PT_HIP(hipEventRecord(B.accumulated, h->stream));
+    spans.push_back({ev + 3, ev + 4, 2});
+    ev += 5;
     h->stats.trace_launches += 1;
     h->stats.accumulate_launches += 1;
     done += iters;
+    batch += 1;
   }
   hipEvent_t e_end = get_event(h, ev++);
   PT_HIP(hipEventRecord(e_end, h->stream));
   PT_HIP(hipGetLastError());
   PT_HIP(hipStreamSynchronize(h->stream));
+  PT_HIP(hipStreamSynchronize(h->trace_stream));
   h->sample_cursor += h->samples_per_step;
 
   unsigned long long counters[2] = {0, 0};
