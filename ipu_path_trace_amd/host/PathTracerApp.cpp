@@ -1,0 +1,246 @@
+#include "PathTracerApp.hpp"
+
+#include <cmath>
+#include <fstream>
+#include <stdexcept>
+#include <thread>
+
+#include "AsyncTask.hpp"
+#include "logging.hpp"
+
+const std::string& OptionMap::str(const std::string& k) const {
+  auto it = values.find(k);
+  if (it == values.end()) throw std::runtime_error("the option '--" + k + "' is required but missing");
+  return it->second;
+}
+
+/// Adjust samples per pixel to be a multiple of samples per step (PathTracerApp.cpp:19-27).
+std::size_t roundSamplesPerPixel(std::size_t samplesPerPixel, std::size_t samplesPerIpuStep) {
+  if (samplesPerPixel % samplesPerIpuStep) {
+    samplesPerPixel += samplesPerIpuStep - (samplesPerPixel % samplesPerIpuStep);
+    pt_log::info_("Rounding SPP to next multiple of {}  (Rounded SPP :=  {})", samplesPerIpuStep, samplesPerPixel);
+  }
+  return samplesPerPixel;
+}
+
+namespace {
+void check(pt_handle h, int rc, const char* what) {
+  if (rc) throw std::runtime_error(std::string(what) + ": " + pt_last_error(h));
+}
+int aaNoiseType(const std::string& s) {
+  if (s == "normal") return PT_AA_NORMAL;
+  if (s == "uniform") return PT_AA_UNIFORM;
+  if (s == "truncated-normal") return PT_AA_TRUNCATED_NORMAL;
+  throw std::runtime_error("Invalid AA noise type: " + s);  // PathTracerApp.cpp:43
+}
+}  // namespace
+
+PathTracerApp::PathTracerApp() {}
+
+PathTracerApp::~PathTracerApp() {
+  for (auto h : devices) pt_destroy(h);
+}
+
+std::vector<OptionSpec> PathTracerApp::addToolOptions() {
+  return {
+      // main.cpp:8-37
+      {"help", 0, "", false, true, "Show command help."},
+      {"model", 0, "false", false, true, "IPU-only (simulator): accepted and ignored."},
+      {"ipus", 0, "1", false, false, "Number of devices to use (MI355X GPUs here)."},
+      {"save-exe", 0, "", false, false, "IPU-only (graph cache): accepted and ignored."},
+      {"load-exe", 0, "", false, false, "IPU-only (graph cache): accepted and ignored."},
+      {"compile-only", 0, "false", false, true, "IPU-only: accepted and ignored."},
+      {"defer-attach", 0, "false", false, true, "IPU-only: accepted and ignored."},
+      {"log-level", 0, "info", false, false, "One of 'trace', 'debug', 'info', 'warn', 'err', 'critical', 'off'."},
+      // PathTracerApp.cpp:794-830
+      {"outfile", 'o', "", true, false, "Set output file name."},
+      {"save-interval", 0, "1", false, false, ""},
+      {"width", 'w', "256", false, false, "Output image width (total pixels)."},
+      {"height", 'h', "256", false, false, "Output image height (total pixels)."},
+      {"samples", 's', "512", false, false, "Total samples to take per pixel."},
+      {"samples-per-step", 0, "512", false, false, "Samples to take per device step."},
+      {"interactive-samples", 0, "8", false, false, "Samples per step during user interaction (UI not built)."},
+      {"refractive-index", 'n', "1.5", false, false, "Refractive index."},
+      {"roulette-depth", 0, "3", false, false, "Number of bounces before rays are randomly stopped."},
+      {"stop-prob", 0, "0.3", false, false, "Probability of a ray being stopped."},
+      {"aa-noise-scale", 'a', "0.3", false, false, "Scale of anti-aliasing noise (pixels)."},
+      {"fov", 0, "90", false, false, "Horizontal field of view (degrees)."},
+      {"exposure", 0, "0", false, false, "Exposure compensation for tone-mapping."},
+      {"gamma", 0, "2.2", false, false, "Gamma correction for tone-mapping."},
+      {"env-map-rotation", 0, "0", false, false, "Azimuthal rotation for HDRI environment map (degrees)."},
+      {"seed", 0, "1", false, false, "Seed for random number generation."},
+      {"aa-noise-type", 0, "normal", false, false, "['uniform', 'normal', 'truncated-normal']."},
+      {"codelet-path", 0, "./", false, false, "IPU-only: accepted and ignored."},
+      {"enable-load-balancing", 0, "false", false, true, "Run dynamic load balancing algorithm for path tracing."},
+      {"max-path-length", 0, "10", false, false, ""},
+      {"assets", 0, "", true, false, "Path to the 'assets.extra' directory of the saved keras model."},
+      {"partials-type", 0, "half", false, false, "IPU-only: accepted and ignored (MFMA accumulates in fp32)."},
+      {"available-memory-proportion", 0, "0.6", false, false, "IPU-only: accepted and ignored."},
+      {"max-nif-batch-size", 0, "44160", false, false, "IPU-only: accepted and ignored (the NIF runs on a compacted queue)."},
+      {"ui-port", 0, "0", false, false, "Remote user-interface (not built: must be 0)."},
+      // additions of this build
+      {"synthetic-nif", 0, "false", false, true, "Use seeded stand-in NIF weights when <assets>/converted.ptnif is absent."},
+      {"constant-env", 0, "", false, false, "r,g,b: constant-radiance environment instead of the NIF (BASELINE config C1)."},
+  };
+}
+
+void PathTracerApp::init(const OptionMap& options) {
+  args = options;
+  samplesPerPixel = args.u32("samples");
+  samplesPerIpuStep = args.u32("samples-per-step");
+  samplesPerPixel = (std::uint32_t)roundSamplesPerPixel(samplesPerPixel, samplesPerIpuStep);
+  if (args.u32("ui-port") != 0) throw std::runtime_error("The remote user interface is not part of this build (--ui-port must be 0).");
+  if (!args.has("constant-env") || args.str("constant-env").empty()) {
+    if (!loadNifModels(args.u32("ipus"), args.str("assets"))) throw std::runtime_error("Could not load NIF model.");
+  }
+}
+
+bool PathTracerApp::loadNifModels(std::size_t numDevices, const std::string& assetPath) {
+  try {
+    const auto metaFile = assetPath + "/nif_metadata.txt";
+    const auto weightFile = assetPath + "/converted.ptnif";
+    std::shared_ptr<NifModel::Data> nifData;
+    if (std::ifstream(weightFile).good()) {
+      nifData = std::make_shared<NifModel::Data>(weightFile, metaFile);
+    } else if (args.flag("synthetic-nif")) {
+      pt_log::warn_("'{}' not found: using seeded synthetic NIF weights", weightFile);
+      nifData = NifModel::Data::synthetic(metaFile, 2024u);
+    } else {
+      throw std::runtime_error("'" + weightFile + "' not found (convert the Keras converted.hdf5 with "
+                               "tools/hdf5_to_ptnif.py, or pass --synthetic-nif)");
+    }
+    models.clear();
+    for (std::size_t c = 0; c < numDevices; ++c)
+      models.push_back(std::make_unique<NifModel>(nifData, "env_nif_gpu" + std::to_string(c)));
+  } catch (std::exception& e) {
+    pt_log::error_("Could not load NIF model from '{}'. Exception: {}", assetPath, e.what());
+    return false;
+  }
+  return true;
+}
+
+void PathTracerApp::attach() {
+  const auto imageWidth = args.u32("width"), imageHeight = args.u32("height");
+  const std::size_t numDevices = args.u32("ipus");
+  geometry.numTiles *= numDevices;  // tiles scale with the device count as on a multi-IPU target
+  const auto raysPerJob = calculateMaxRaysPerTile(imageWidth, imageHeight, geometry);
+  ipuJobs.reserve(geometry.numTiles);
+  for (std::size_t t = 0; t < geometry.numTiles; ++t) ipuJobs.emplace_back(raysPerJob, t);
+  const std::size_t itemsPerDevice = raysPerJob * (geometry.numTiles / numDevices);
+  for (std::size_t d = 0; d < numDevices; ++d) {
+    pt_config cfg{};
+    cfg.struct_size = sizeof(pt_config);
+    cfg.width = imageWidth;
+    cfg.height = imageHeight;
+    cfg.max_path_length = args.u32("max-path-length");
+    cfg.roulette_depth = args.u32("roulette-depth");
+    cfg.stop_prob = args.f32("stop-prob");
+    cfg.refractive_index = args.f32("refractive-index");
+    cfg.aa_noise_type = aaNoiseType(args.str("aa-noise-type"));
+    cfg.sample_precision = PT_SAMPLES_HALF;
+    cfg.device = (std::int32_t)d;
+    cfg.max_work_items = (std::uint32_t)itemsPerDevice;
+    pt_handle h = nullptr;
+    if (pt_create(&cfg, &h)) throw std::runtime_error(std::string("Could not attach to device: ") + pt_last_error(nullptr));
+    devices.push_back(h);
+  }
+  pt_log::info_("Tracebuffer shape: [{}, {}]", ipuJobs.size(), sizeof(TraceRecord) * raysPerJob);
+}
+
+void PathTracerApp::initialiseState(std::uint32_t imageWidth, std::uint32_t imageHeight) {
+  auto jobs = createTracingJobs(imageWidth, imageHeight, geometry);
+  pt_log::info_("Created worklists for {} tiles", jobs.size());
+  traceState = std::make_unique<PathTracerState>(imageWidth, imageHeight, jobs.size() * jobs.front().size());
+  traceState->work.randomiseWorkList(jobs);
+  traceState->work.getWork().active() = traceState->work.getWork().inactive();
+}
+
+void PathTracerApp::execute() {
+  const auto imageWidth = args.u32("width"), imageHeight = args.u32("height");
+  const auto seed = args.u64("seed");
+  const float antiAliasingScale = args.f32("aa-noise-scale");
+  const float fieldOfView = args.f32("fov") * (float)(M_PI / 180.f);      // PathTracerApp.cpp:574
+  const float configExposure = args.f32("exposure"), configGamma = args.f32("gamma");
+  const auto fileName = args.str("outfile");
+  const bool loadBalanceEnabled = args.flag("enable-load-balancing");
+  const auto saveInterval = args.u32("save-interval");
+  const auto steps = samplesPerPixel / samplesPerIpuStep;
+  const float degrees = args.f32("env-map-rotation");
+  const float radians = (degrees / 360.f) * (float)(2.0 * M_PI);          // PathTracerApp.cpp:584
+
+  auto startTime = std::chrono::steady_clock::now();
+
+  // programs init_nif_weights and init_render_settings (PathTracerApp.cpp:612-614)
+  for (std::size_t d = 0; d < devices.size(); ++d) {
+    if (args.has("constant-env") && !args.str("constant-env").empty()) {
+      float rgb[3] = {1, 1, 1};
+      if (std::sscanf(args.str("constant-env").c_str(), "%f,%f,%f", &rgb[0], &rgb[1], &rgb[2]) != 3)
+        throw std::runtime_error("--constant-env expects r,g,b");
+      check(devices[d], pt_set_constant_env(devices[d], rgb), "set_constant_env");
+    } else {
+      models[d]->analyseModel((std::size_t)imageWidth * imageHeight / devices.size());
+      models[d]->upload(devices[d]);
+    }
+    check(devices[d], pt_set_render_settings(devices[d], seed, antiAliasingScale, fieldOfView, radians, samplesPerIpuStep),
+          "init_render_settings");
+  }
+  initialiseState(imageWidth, imageHeight);
+
+  AsyncTask hostProcessing;
+  pt_log::info_("Render started");
+  std::size_t totalRays = 0;
+  const std::size_t itemsPerDevice = traceState->work.getWork().active().size() / devices.size();
+
+  for (auto step = 1u; step <= steps; ++step) {
+    auto loopStartTime = std::chrono::steady_clock::now();
+
+    // setup -> path_trace -> read_results on every device (PathTracerApp.cpp:692-694).  The worklist is
+    // cut into equal contiguous slices, one per device, as tiles are cut over IPUs; devices run
+    // concurrently and exchange nothing (PathTracerApp.cpp:205-252).
+    auto& active = traceState->work.getWork().active();
+    std::vector<std::thread> runners;
+    std::vector<std::string> errors(devices.size());
+    std::vector<pt_stats> stats(devices.size());
+    for (std::size_t d = 0; d < devices.size(); ++d) {
+      runners.emplace_back([&, d]() {
+        auto* slice = reinterpret_cast<pt_trace_record*>(active.data() + d * itemsPerDevice);
+        pt_handle h = devices[d];
+        if (pt_setup(h, slice, itemsPerDevice) || pt_path_trace(h) || pt_read_results(h, slice, itemsPerDevice, &stats[d]))
+          errors[d] = pt_last_error(h);
+      });
+    }
+    for (auto& t : runners) t.join();
+    for (auto& e : errors) if (!e.empty()) throw std::runtime_error("Device step failed: " + e);
+    pt_log::debug_("Path-Trace ms: {}", stats[0].path_trace_ms);
+    pt_log::debug_("NIF ms: {}", stats[0].nif_ms);
+    pt_log::debug_("Total ms per step: {}", stats[0].total_ms);
+
+    hostProcessing.waitForCompletion();    // join the previous async task before swapping (:703-708)
+    traceState->work.getWork().swap();
+
+    hostProcessing.run([&, step, workPtr = &traceState->work, filmPtr = &traceState->film]() {
+      filmPtr->accumulate(workPtr->getWork().inactive());
+      if (loadBalanceEnabled && step > 1) workPtr->allocateWorkByPathLength(ipuJobs);
+      totalRays = workPtr->clearInactiveAccumulators();
+      if (step % saveInterval == 0 || step == steps) {
+        filmPtr->saveImages(fileName, step, configExposure, configGamma);
+        pt_log::info_("Saved images at step {}", step);
+      }
+    });
+
+    auto loopEndTime = std::chrono::steady_clock::now();
+    auto secs = std::chrono::duration<double>(loopEndTime - loopStartTime).count();
+    const auto pixelSamplesPerStep = (double)imageWidth * imageHeight * samplesPerIpuStep;
+    pt_log::info_("Completed render step {}/{} in {} seconds (Samples/sec {}) (Rays/sec {})", step, steps, secs,
+                  pixelSamplesPerStep / secs, totalRays / secs);
+  }
+  hostProcessing.waitForCompletion();
+
+  auto endTime = std::chrono::steady_clock::now();
+  const auto elapsedSecs = std::chrono::duration<double>(endTime - startTime).count();
+  pt_log::info_("Render finished: {} seconds", elapsedSecs);
+  const std::size_t pixelsPerFrame = (std::size_t)imageWidth * imageHeight;
+  finalSamplesPerSec = (pixelsPerFrame / elapsedSecs) * samplesPerPixel;   // PathTracerApp.cpp:786-789
+  pt_log::info_("Samples/sec: {}", finalSamplesPerSec);
+  pt_log::info_("Samples/sec/tile: {}", finalSamplesPerSec / ipuJobs.size());
+}

@@ -1,0 +1,81 @@
+// extern "C" test shim over the host classes (for the Python test-suite; not part of the product boundary).
+#include <cstring>
+#include <string>
+
+#include "AccumulatedImage.hpp"
+#include "LoadBalancer.hpp"
+#include "NifModel.hpp"
+#include "PathTracerApp.hpp"
+#include "image_io.hpp"
+
+extern "C" {
+
+std::size_t pth_calculate_max_rays_per_tile(std::size_t w, std::size_t h, std::size_t tiles, std::size_t workers) {
+  DeviceGeometry g{tiles, workers};
+  return calculateMaxRaysPerTile(w, h, g);
+}
+
+// Fills `out` (tiles * rays-per-tile records) with the shuffled, padded worklist; returns the record count.
+std::size_t pth_make_shuffled_worklist(std::size_t w, std::size_t h, std::size_t tiles, std::size_t workers, TraceRecord* out,
+                                       std::size_t capacity) {
+  DeviceGeometry g{tiles, workers};
+  auto jobs = createTracingJobs(w, h, g);
+  LoadBalancer lb(jobs.size() * jobs.front().size());
+  lb.randomiseWorkList(jobs);
+  auto& list = lb.getWork().inactive();
+  if (out && capacity >= list.size()) std::memcpy(out, list.data(), list.size() * sizeof(TraceRecord));
+  return list.size();
+}
+
+// allocateWorkByPathLength + clearInactiveAccumulators on a caller-supplied list (in place); returns the path-length sum.
+std::size_t pth_balance_and_clear(TraceRecord* records, std::size_t n, std::size_t jobs, int balance) {
+  LoadBalancer lb(n);
+  lb.getWork().inactive().assign(records, records + n);
+  if (balance) {
+    IpuJobList jl;
+    for (std::size_t j = 0; j < jobs; ++j) jl.emplace_back(n / jobs, j);
+    lb.allocateWorkByPathLength(jl);
+  }
+  if (balance) std::memcpy(records, lb.getWork().inactive().data(), n * sizeof(TraceRecord));   // balanced order, lengths intact
+  std::size_t sum = lb.clearInactiveAccumulators();
+  if (!balance) std::memcpy(records, lb.getWork().inactive().data(), n * sizeof(TraceRecord));  // cleared accumulators
+  return sum;
+}
+
+// Accumulate `steps` identical record lists into a film, tone-map, save; copies the HDR (BGR) film out.
+int pth_film_roundtrip(const TraceRecord* records, std::size_t n, std::size_t w, std::size_t h, std::size_t steps, float exposure,
+                       float gamma, const char* file, float* hdr_out, unsigned char* ldr_out) {
+  try {
+    AccumulatedImage film(w, h);
+    std::vector<TraceRecord> v(records, records + n);
+    for (std::size_t s = 0; s < steps; ++s) film.accumulate(v);
+    auto hdr = film.getHdrImage();
+    std::memcpy(hdr_out, hdr.data.data(), hdr.data.size() * sizeof(float));
+    const auto& ldr = film.updateLdrImage(steps, exposure, gamma);
+    std::memcpy(ldr_out, ldr.data.data(), ldr.data.size());
+    if (file && *file) film.saveImages(file, steps, exposure, gamma);
+    return 0;
+  } catch (...) { return -1; }
+}
+
+int pth_read_exr(const char* file, float* bgr, std::size_t capacity, std::size_t* w, std::size_t* h) {
+  std::vector<float> d;
+  if (!image_io::readExr(file, d, *w, *h)) return -1;
+  if (d.size() > capacity) return -2;
+  std::memcpy(bgr, d.data(), d.size() * sizeof(float));
+  return 0;
+}
+
+// Parses nif_metadata.txt; out = {embedding, hidden, layers, logToneMap, max, mean[3] (eps folded)}.
+int pth_read_metadata(const char* file, double* out8) {
+  try {
+    NifMetaData m(file);
+    out8[0] = (double)m.embeddingDimension; out8[1] = (double)m.hiddenSize; out8[2] = (double)m.layerCount;
+    out8[3] = m.logToneMap; out8[4] = m.max; out8[5] = m.mean[0]; out8[6] = m.mean[1]; out8[7] = m.mean[2];
+    return 0;
+  } catch (...) { return -1; }
+}
+
+std::size_t pth_round_samples(std::size_t spp, std::size_t per_step) { return roundSamplesPerPixel(spp, per_step); }
+
+}  // extern "C"

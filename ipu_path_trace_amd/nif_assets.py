@@ -91,3 +91,36 @@ def flops_per_sample(layers):
         if b is not None:
             f += k.shape[1]
     return f
+
+
+def write_ptnif(path, layers, embedding_dim):
+    """Flat side-car weight file read by the C++ host (ipu_path_trace_amd/host/NifModel.cpp: setupModel).
+
+    Stands in for <assets>/converted.hdf5 (reference src/keras/Hdf5Model.cpp:62-87), which needs libhdf5.
+    Layout: b"PTNIF1\0\0", u32 n_layers, u32 embedding_dim, then per layer u32 rows, cols, dtype (0 = float16),
+    relu, has_bias followed by the raw kernel bytes [rows][cols] and the bias bytes [cols].
+    """
+    import struct
+    with open(path, "wb") as f:
+        f.write(b"PTNIF1\0\0")
+        f.write(struct.pack("<II", len(layers), embedding_dim))
+        for k, b, relu in layers:
+            k = np.ascontiguousarray(k, dtype=np.float16)
+            f.write(struct.pack("<IIIII", k.shape[0], k.shape[1], 0, int(bool(relu)), int(b is not None)))
+            f.write(k.tobytes())
+            if b is not None:
+                f.write(np.ascontiguousarray(b, dtype=np.float16).tobytes())
+
+
+def write_metadata(path, meta=URBAN_ALLEY_META):
+    """nif_metadata.txt with the fields NifMetaData.cpp reads."""
+    doc = {
+        "embedding_dimension": meta["embedding_dimension"],
+        "encode_params": {"eps": meta["eps"], "log_tone_map": meta["log_tone_map"], "max": meta["max"],
+                          "mean": meta["mean"], "transfer_function": "log"},
+        "name": "synthetic", "original_image_shape": meta["original_image_shape"],
+        "train_command": ["train_nif.py", "--layer-count", str(meta["layer_count"]), "--layer-size",
+                          str(meta["hidden_size"]), "--embedding-dimension", str(meta["embedding_dimension"])],
+    }
+    with open(path, "w") as f:
+        json.dump(doc, f, indent=2)

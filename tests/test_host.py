@@ -1,0 +1,187 @@
+"""Host-side C++ mirror of the reference interface (ipu_path_trace_amd/host) through its extern "C" test shim."""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from ipu_path_trace_amd import nif_assets
+from ipu_path_trace_amd.ptmi import TRACE_DTYPE
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "ipu_path_trace_amd", "host")
+
+
+@pytest.fixture(scope="module")
+def host():
+    subprocess.check_call(["make", "-C", HOST, "-s"])
+    L = C.CDLL(os.path.join(HOST, "libpthost.so"))
+    st = C.c_size_t
+    L.pth_calculate_max_rays_per_tile.restype = st
+    L.pth_calculate_max_rays_per_tile.argtypes = [st, st, st, st]
+    L.pth_make_shuffled_worklist.restype = st
+    L.pth_make_shuffled_worklist.argtypes = [st, st, st, st, C.c_void_p, st]
+    L.pth_balance_and_clear.restype = st
+    L.pth_balance_and_clear.argtypes = [C.c_void_p, st, st, C.c_int]
+    L.pth_film_roundtrip.argtypes = [C.c_void_p, st, st, st, st, C.c_float, C.c_float, C.c_char_p, C.c_void_p, C.c_void_p]
+    L.pth_read_exr.argtypes = [C.c_char_p, C.c_void_p, st, C.POINTER(st), C.POINTER(st)]
+    L.pth_read_metadata.argtypes = [C.c_char_p, C.c_void_p]
+    L.pth_round_samples.restype = st
+    L.pth_round_samples.argtypes = [st, st]
+    return L
+
+
+def test_calculate_max_rays_per_tile_table(host):
+    """LoadBalancer.cpp:14-36 including its `r += r % workers` rounding (values verified in SURVEY.md 8(c))."""
+    f = host.pth_calculate_max_rays_per_tile
+    assert f(256, 256, 1472, 6) == 48          # ceil(65536/1472)=45 -> 45 + 45%6 = 48
+    assert f(1104, 1000, 1472, 6) == 750
+    assert f(3840, 2160, 1472, 6) == 5636       # 5635 -> 5636
+    assert f(526, 526, 1472, 6) == 190          # 188 -> 190 (not a multiple of 6)
+    assert f(4, 4, 1472, 6) == 6                # minimum = worker count
+    assert host.pth_round_samples(100000, 300) == 100200 and host.pth_round_samples(512, 512) == 512
+
+
+def test_shuffled_padded_worklist(host):
+    w, h, tiles, workers = 100, 70, 64, 6
+    n = host.pth_make_shuffled_worklist(w, h, tiles, workers, None, 0)
+    per = host.pth_calculate_max_rays_per_tile(w, h, tiles, workers)
+    assert n == per * tiles >= w * h
+    rec = np.zeros(n, dtype=TRACE_DTYPE)
+    assert host.pth_make_shuffled_worklist(w, h, tiles, workers, rec.ctypes.data, n) == n
+    pad = (rec["u"] == 65535) & (rec["v"] == 65535)   # LoadBalancer.cpp:66-71
+    assert pad.sum() == n - w * h
+    real = rec[~pad]
+    key = real["v"].astype(np.int64) * w + real["u"]
+    assert np.array_equal(np.sort(key), np.arange(w * h))          # every pixel exactly once
+    assert not np.array_equal(key, np.arange(w * h))               # shuffled (mt19937 seed 142)
+    rec2 = np.zeros(n, dtype=TRACE_DTYPE)
+    host.pth_make_shuffled_worklist(w, h, tiles, workers, rec2.ctypes.data, n)
+    assert rec.tobytes() == rec2.tobytes()                         # deterministic
+    assert np.all(rec["r"] == 0) and np.all(rec["sampleCount"] == 0)
+
+
+def test_balance_by_path_length_and_clear(host):
+    rng = np.random.default_rng(0)
+    jobs, per = 8, 10
+    rec = np.zeros(jobs * per, dtype=TRACE_DTYPE)
+    rec["u"] = np.arange(rec.size)
+    rec["pathLength"] = rng.integers(1, 200, rec.size)
+    rec["r"] = 1.0
+    rec["sampleCount"] = 3
+    before = rec.copy()
+    total = host.pth_balance_and_clear(rec.ctypes.data, rec.size, jobs, 1)
+    assert total == int(before["pathLength"].astype(np.int64).sum())
+    assert sorted(rec["u"].tolist()) == list(range(rec.size))       # a permutation of the items
+    # every job received pairs (shortest, longest): per-job sums of the path lengths are balanced
+    lengths = rec["pathLength"].reshape(jobs, per).astype(np.int64)
+    assert lengths.sum(axis=1).max() - lengths.sum(axis=1).min() < 0.35 * lengths.sum(axis=1).mean()
+    s = np.sort(before["pathLength"])
+    assert lengths[0, 0] == s[0] and lengths[0, 1] == s[-1]
+    # clearInactiveAccumulators (LoadBalancer.cpp:198-213): zero r,g,b,sampleCount,pathLength, keep u,v, return the sum
+    rec2 = before.copy()
+    assert host.pth_balance_and_clear(rec2.ctypes.data, rec2.size, jobs, 0) == total
+    assert np.all(rec2["pathLength"] == 0) and np.all(rec2["r"] == 0) and np.all(rec2["sampleCount"] == 0)
+    assert np.array_equal(rec2["u"], before["u"])
+
+
+def test_film_accumulate_tonemap_and_exr(host, tmp_path):
+    w, h, steps = 12, 7, 3
+    rec = np.zeros(w * h + 5, dtype=TRACE_DTYPE)
+    rr, cc = np.divmod(np.arange(w * h), w)
+    rec["u"][: w * h], rec["v"][: w * h] = cc, rr
+    rec["u"][w * h:] = 65535
+    rec["v"][w * h:] = 65535                                        # padding is skipped (AccumulatedImage.cpp:66-67)
+    rng = np.random.default_rng(1)
+    for c in "rgb":
+        rec[c] = rng.random(rec.size).astype(np.float32) * 4
+    rec["sampleCount"] = 4
+    hdr = np.zeros((h, w, 3), dtype=np.float32)
+    ldr = np.zeros((h, w, 3), dtype=np.uint8)
+    out = str(tmp_path / "img.png")
+    assert host.pth_film_roundtrip(rec.ctypes.data, rec.size, w, h, steps, 0.5, 2.2, out.encode(), hdr.ctypes.data,
+                                   ldr.ctypes.data) == 0
+    exp = np.zeros((h, w, 3), dtype=np.float32)
+    for _ in range(steps):                                          # hdr(v,u) += (b,g,r)/sampleCount
+        exp[rr, cc, 0] += rec["b"][: w * h] * np.float32(0.25)
+        exp[rr, cc, 1] += rec["g"][: w * h] * np.float32(0.25)
+        exp[rr, cc, 2] += rec["r"][: w * h] * np.float32(0.25)
+    np.testing.assert_array_equal(hdr, exp)
+    tone = np.power(exp / steps * np.float32(2 ** 0.5), 1 / 2.2) * 255.0
+    assert np.abs(ldr.astype(np.int32) - np.clip(np.rint(tone), 0, 255).astype(np.int32)).max() <= 1
+    # the files: PNG decodes to the LDR image (RGB order), EXR holds hdr/steps in B,G,R channels
+    from PIL import Image
+    png = np.asarray(Image.open(out))
+    assert png.shape == (h, w, 3) and np.array_equal(png[..., ::-1], ldr)
+    back = np.zeros((h, w, 3), dtype=np.float32)
+    ww, hh = C.c_size_t(), C.c_size_t()
+    assert host.pth_read_exr(str(tmp_path / "img.exr").encode(), back.ctypes.data, back.size, C.byref(ww), C.byref(hh)) == 0
+    assert (ww.value, hh.value) == (w, h)
+    np.testing.assert_allclose(back, exp / steps, rtol=1e-6)
+
+
+def test_metadata_parser_matches_reference_fixture(host, tmp_path):
+    """The C++ parser on a file with the reference's nif_metadata.txt fields (values from the real fixture)."""
+    p = tmp_path / "nif_metadata.txt"
+    nif_assets.write_metadata(str(p))
+    out = (C.c_double * 8)()
+    assert host.pth_read_metadata(str(p).encode(), out) == 0
+    assert list(out[:4]) == [12, 320, 6, 1]
+    assert out[4] == pytest.approx(3.4299468994140625)
+    np.testing.assert_allclose(list(out[5:8]), nif_assets.folded_mean(), rtol=1e-7)
+    bad = tmp_path / "bad.txt"
+    bad.write_text("{\"embedding_dimension\": 12}")
+    assert host.pth_read_metadata(str(bad).encode(), out) == -1
+    assert host.pth_read_metadata(str(tmp_path / "missing.txt").encode(), out) == -1
+
+
+def test_cli_contract_without_gpu(host, tmp_path):
+    """CLI surface of main.cpp:8-37 + PathTracerApp.cpp:794-830: names, short forms, required options, errors."""
+    exe = os.path.join(HOST, "ipu_trace")
+    help_text = subprocess.run([exe, "--help"], capture_output=True, text=True).stdout
+    for opt in ["--outfile", "--save-interval", "--width", "--height", "--samples", "--samples-per-step",
+                "--interactive-samples", "--refractive-index", "--roulette-depth", "--stop-prob", "--aa-noise-scale",
+                "--fov", "--exposure", "--gamma", "--env-map-rotation", "--seed", "--aa-noise-type", "--codelet-path",
+                "--enable-load-balancing", "--max-path-length", "--assets", "--partials-type",
+                "--available-memory-proportion", "--max-nif-batch-size", "--ui-port", "--model", "--ipus", "--save-exe",
+                "--load-exe", "--compile-only", "--defer-attach", "--log-level"]:
+        assert opt in help_text, opt
+    for short in ["-o", "-w", "-h", "-s", "-n", "-a"]:
+        assert "[ %s ]" % short in help_text
+    r = subprocess.run([exe, "-w", "32"], capture_output=True, text=True)
+    assert r.returncode != 0 and "required but missing" in r.stdout
+    r = subprocess.run([exe, "-o", "x.png", "--assets", str(tmp_path), "--bogus"], capture_output=True, text=True)
+    assert r.returncode != 0 and "unrecognised option" in r.stdout
+    r = subprocess.run([exe, "-o", "x.png", "--assets", str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode != 0 and "Could not load NIF model" in r.stdout    # PathTracerApp.cpp:69-71
+
+
+@pytest.mark.gpu
+def test_ipu_trace_end_to_end_matches_oracle(host, oracle, tmp_path):
+    """Drop-in CLI on the GPU: shuffled padded worklist, two steps, film accumulate, EXR; against the oracle."""
+    O = oracle
+    exe = os.path.join(HOST, "ipu_trace")
+    W, H, spp, steps = 96, 64, 5, 2
+    assets = tmp_path / "assets.extra"
+    assets.mkdir()
+    layers = nif_assets.synthetic_nif()
+    nif_assets.write_metadata(str(assets / "nif_metadata.txt"))
+    nif_assets.write_ptnif(str(assets / "converted.ptnif"), layers, 12)
+    out = tmp_path / "img.png"
+    r = subprocess.run([exe, "--assets", str(assets), "-w", str(W), "-h", str(H), "-s", str(spp * steps),
+                        "--samples-per-step", str(spp), "--max-path-length", "6", "--env-map-rotation", "30",
+                        "-o", str(out), "--save-interval", "1", "--ipus", "1", "--defer-attach"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "Completed render step 2/2" in r.stdout and "Samples/sec:" in r.stdout
+    film = np.zeros((H, W, 3), dtype=np.float32)
+    ww, hh = C.c_size_t(), C.c_size_t()
+    assert host.pth_read_exr(str(tmp_path / "img.exr").encode(), film.ctypes.data, film.size, C.byref(ww), C.byref(hh)) == 0
+    cfg = O.make_config(width=W, height=H, max_path_length=6, env_mode=O.ENV_NIF, env_rotation_degrees=30.0)
+    ref = O.worklist(W, H)
+    O.render(cfg, O.Nif(layers, 12, nif_assets.URBAN_ALLEY_META["max"], nif_assets.folded_mean()), ref, 0, spp * steps)
+    exp = np.stack([ref["b"], ref["g"], ref["r"]], -1).reshape(H, W, 3) / (spp * steps)
+    np.testing.assert_allclose(film, exp, rtol=2e-2, atol=1e-6)
+    assert os.path.getsize(out) > 1000
