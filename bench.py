@@ -24,6 +24,16 @@ sys.path.insert(0, ROOT)
 MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense fp16/bf16
 
 
+def hbm_traffic_from_profile():
+    """HBM bytes per NIF-kernel launch from the committed PMC passes (counters cannot be read inside this process)."""
+    path = os.path.join(ROOT, "profiles", "r01_d_pmc_hbm.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["nif_kernel_v3"]["hbm_bytes_per_launch_corrected"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(width, height, depth, layers, meta, mean, target_seconds=12.0):
     """Time the CPU oracle (a restatement -- upstream external/light is not vendored) on this host's cores,
     on a bounded pixel subset of the same workload at 1 spp."""
@@ -146,11 +156,13 @@ def main():
                        "trace_dtype": "f32", "nif_flops_per_sample": flops,
                        "escaped_fraction": agg["escaped"] / max(agg["paths"], 1),
                        "segments_per_path": agg["segments"] / max(agg["paths"], 1)},
-            "roofline": {"bound": "mfma", "kernel": "nif_kernel<%d,12,2>" % args.hidden,
+            "roofline": {"bound": "mfma", "kernel": "nif_kernel_v3<%d,12,8,2>" % args.hidden,
                          "achieved": achieved, "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_F16_DENSE_PEAK_TFLOPS,
                          "avg_launch_ms": agg["nif_ms"] / max(agg["nif_launches"], 1),
-                         "launches": agg["nif_launches"], "traffic": None,
+                         "launches": agg["nif_launches"], "traffic": hbm_traffic_from_profile(),
+                         "traffic_unit": "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes: "
+                                         "profiles/r01_d_pmc_hbm.json)",
                          "rank0_stage_ms": {"trace": agg["trace_ms"], "nif": agg["nif_ms"], "accumulate": agg["acc_ms"]}},
         }
         if world == 1 and not args.no_cpu_baseline:
