@@ -353,7 +353,21 @@ void launch_nif_t(pt_handle h, const ptd::NifParams& N, int blocks) {
   else launch_nif_v3<HID, E, 8, 2>(h, N, blocks);
 }
 
+template <int HID, int E>
+void launch_nif_wide(pt_handle h, const ptd::NifParams& N, int blocks) {
+  constexpr int lds = (HID / 16) * 2 * 1024 + (ptd::kMaxRegions + 1 + 256) * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ptd::nif_wide_kernel<HID, E>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((ptd::nif_wide_kernel<HID, E>), dim3(blocks), dim3(256), lds, h->stream, N);
+}
+
 int launch_nif(pt_handle h, const ptd::NifParams& N, int blocks) {
+  if (h->nif_emb == 12 && h->nif_hidden == 1024) { launch_nif_wide<1024, 12>(h, N, blocks); return PT_OK; }
+  if (h->nif_emb == 12 && h->nif_hidden == 512) { launch_nif_wide<512, 12>(h, N, blocks); return PT_OK; }
   if (h->nif_emb == 12) {
     switch (h->nif_hidden) {
       case 64: launch_nif_t<64, 12>(h, N, blocks); return PT_OK;
@@ -368,7 +382,7 @@ int launch_nif(pt_handle h, const ptd::NifParams& N, int blocks) {
 }
 
 bool nif_shape_supported(uint32_t hidden, uint32_t emb) {
-  if (emb == 12 && (hidden == 64 || hidden == 128 || hidden == 256 || hidden == 320)) return true;
+  if (emb == 12 && (hidden == 64 || hidden == 128 || hidden == 256 || hidden == 320 || hidden == 512 || hidden == 1024)) return true;
   if (emb == 4 && hidden == 64) return true;
   return false;
 }

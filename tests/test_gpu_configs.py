@@ -136,3 +136,38 @@ def test_config_c4_partition_invariance(ptmi_lib):
         parts.append(np.stack([rec["b"], rec["g"], rec["r"]], -1) / np.float32(spp))
     assert np.array_equal(partition.assemble_hdr(W, H, world, parts), film)
     r.close()
+
+
+def test_config_c5_wide_nif_8x1024(oracle, ptmi_lib):
+    """C5: NIF 8x1024 fp16 (14,891,011 FLOP per evaluation) at 1104x1000, depth 8: full-size step properties and a
+    pixel subset against the oracle."""
+    W, H, depth, spp = 1104, 1000, 8, 2
+    layers = nif_assets.synthetic_nif(hidden=1024, layer_count=8, seed=31)
+    meta = nif_assets.URBAN_ALLEY_META
+    r = ptmi_lib.Renderer(W, H, max_path_length=depth)
+    r.init_nif_weights(layers, 12, meta["max"], nif_assets.folded_mean())
+    r.init_render_settings(samples_per_step=spp)
+    work = partition.tile_order_worklist(W, H)
+    r.setup(work)
+    r.path_trace()
+    st = r.read_results(work)
+    assert st.nif_flops_per_sample == 14891011 and st.paths == W * H * spp
+    assert np.all(work["sampleCount"] == spp)
+    img = np.stack([work["r"], work["g"], work["b"]], -1)
+    assert np.all(np.isfinite(img)) and img.min() >= 0
+    r.init_render_settings(seed=4, samples_per_step=spp)
+    r.init_render_settings(seed=1, samples_per_step=spp)
+    rng = np.random.default_rng(21)
+    rec = np.zeros(600, dtype=ptmi_lib.TRACE_DTYPE)
+    rec["u"] = rng.integers(0, W, rec.size)
+    rec["v"] = rng.integers(H // 3, H, rec.size)
+    ref = rec.copy()
+    r.setup(rec)
+    r.path_trace()
+    r.read_results(rec)
+    cfg = oracle.make_config(width=W, height=H, max_path_length=depth, env_mode=oracle.ENV_NIF)
+    oracle.render(cfg, oracle.Nif(layers, 12, meta["max"], nif_assets.folded_mean()), ref, 0, spp)
+    assert np.array_equal(rec["pathLength"], ref["pathLength"])
+    for c in "rgb":
+        np.testing.assert_allclose(rec[c], ref[c], rtol=NIF_RTOL, atol=1e-6)
+    r.close()
