@@ -591,6 +591,8 @@ struct NifV3Geometry {
   static constexpr int R = 3;
   static constexpr int SLAB_PIECES = ((TPS * (KS + IS) + WAVES - 1) / WAVES) * WAVES;
   static constexpr int PW = SLAB_PIECES / WAVES;
+  // pieces per wave of the smallest slabs (the head: KS pieces; layer 0: >= 2 tiles x IS pieces)
+  static constexpr int MINP = (KS >= 2 * WAVES && 2 * IS * 2 >= WAVES) ? 2 : ((KS >= WAVES) ? 1 : 0);
   static constexpr int SLOT_BYTES = SLAB_PIECES * 1024;
   static constexpr int T0 = (SLAB_PIECES / IS) < NT ? (SLAB_PIECES / IS) : NT;   // layer-0 tiles per slab
   static constexpr int SCAN_BYTES = ((kMaxRegions + 1) * 4 + 511) / 512 * 512;
@@ -669,8 +671,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void nif_kernel_v3(const Nif
   };
   auto slab_piece = [&](int i) {
     if constexpr (DIAG & 1) return;
-    uint32_t piece = (uint32_t)wave + (uint32_t)WAVES * i;
-    if (piece >= pf_cnt) piece = pf_cnt - 1u;        // uniform load count: re-load the last piece
+    const uint32_t piece = (uint32_t)wave + (uint32_t)WAVES * i;
+    if (piece >= pf_cnt) return;                     // exact counts: a wave issues ceil((cnt - wave) / WAVES) pieces
     const char* src = reinterpret_cast<const char*>(P.wpack) + ((size_t)(pf_first + piece) * 1024 + lane * 16);
     glds16(src, pf_slot + piece * 1024u);
   };
@@ -697,7 +699,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void nif_kernel_v3(const Nif
 #pragma unroll
       for (int k = 0; k < PW; ++k) if (k >= pf_next) slab_piece(k);   // pieces a short stage had no room for
       if (pf_next != PW + 1) slab_end();
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW * (R - 2)) : "memory");
+      // Counted wait.  Piece counts are exact, so waves and slabs differ in how many pieces they have in flight;
+      // every wave issues at least MINP pieces for every slab, so leaving MINP in flight guarantees that all of
+      // THIS stage's pieces (older than the next slab's) have landed.  DMA latency is hidden either way
+      // (profiles/r01_c_nif_ablation.txt, DIAG 16).
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::MINP * (R - 2)) : "memory");
       asm volatile("s_barrier" ::: "memory");
       slab_begin();
       pf_next = 0;
@@ -875,7 +881,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void nif_kernel_v3(const Nif
               epi_chunk(pend, gc, dst[2 * (j - 1)], dst[2 * (j - 1) + 1], b_now);
             }
           }
-          dma_slot();
+          // DMA riders behind groups 4.. of each tile, away from the epilogue chunks of groups 0..3
+          if constexpr (NG >= 8) { if constexpr (g2 >= 4 && g2 < 4 + (PW + TPS - 1) / TPS) dma_slot(); }
+          else dma_slot();
         });
         if (j > 0) {   // narrow networks: fewer than four groups per tile, finish the leftover chunks here
           if constexpr (NG < 2) epi_chunk(pend, IC<1>{}, dst[2 * (j - 1)], dst[2 * (j - 1) + 1], bias_at(pend, 1));
@@ -932,10 +940,6 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void nif_kernel_v3(const Nif
         }
       }
     }
-  }
-  if constexpr (!(DIAG & 1)) {
-#pragma unroll
-    for (int k = 0; k < PW; ++k) if (k >= pf_next) slab_piece(k);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the run-ahead DMA before the wave ends
 }
