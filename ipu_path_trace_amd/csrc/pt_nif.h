@@ -1038,16 +1038,33 @@ __global__ __launch_bounds__(256, 1) void nif_wide_kernel(const NifParams P) {
     };
     // k-steps over the LDS-resident activations, weights from L2, four pieces in flight per group
     auto mma_act = [&](const uint4* wj, f32x16 (&acc)[NB]) __attribute__((always_inline)) {
-      for (int s0 = 0; s0 < KS; s0 += 4) {
-        half8 a[4];
+      // weight pieces come from L2 with ~1 us latency: two groups of GW pieces in flight (register double buffer)
+      constexpr int GW = 8;
+      static_assert(KS % (2 * GW) == 0, "k-steps are consumed in pairs of groups");
+      uint4 w0[GW], w1[GW];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = as_half8(wj[(size_t)(s0 + i) * 64]);
+      for (int i = 0; i < GW; ++i) w0[i] = wj[(size_t)i * 64];
+      for (int s0 = 0; s0 < KS; s0 += 2 * GW) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < GW; ++i) w1[i] = wj[(size_t)(s0 + GW + i) * 64];
+#pragma unroll
+        for (int i = 0; i < GW; ++i) {
 #pragma unroll
           for (int b = 0; b < NB; ++b) {
             const half8 bf = as_half8(act[((size_t)(s0 + i) * NB + b) * 64 + lane]);
-            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], bf, acc[b], 0, 0, 0);
+            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(w0[i]), bf, acc[b], 0, 0, 0);
+          }
+        }
+        if (s0 + 2 * GW < KS) {
+#pragma unroll
+          for (int i = 0; i < GW; ++i) w0[i] = wj[(size_t)(s0 + 2 * GW + i) * 64];
+        }
+#pragma unroll
+        for (int i = 0; i < GW; ++i) {
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            const half8 bf = as_half8(act[((size_t)(s0 + GW + i) * NB + b) * 64 + lane]);
+            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(w1[i]), bf, acc[b], 0, 0, 0);
           }
         }
       }
