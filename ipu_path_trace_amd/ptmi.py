@@ -67,6 +67,12 @@ def load_library():
     if not os.path.exists(path):
         raise FileNotFoundError(
             "%s not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()')" % path)
+    try:
+        # torch bundles its own HIP runtime: when both live in one process it has to be loaded first, or torch later
+        # finds "No HIP GPUs" (two copies of libamdhip64 with one SONAME).  No torch, no problem.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(path)
     L.pt_abi_version.restype = C.c_int
     L.pt_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]

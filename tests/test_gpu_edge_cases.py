@@ -1,0 +1,142 @@
+"""Edge cases of the boundary on the GPU: empty and ragged worklists, padding items, NIF hot-swap, accumulator clear,
+device-side HDR export, several handles at once, seeds."""
+import numpy as np
+import pytest
+
+from ipu_path_trace_amd import nif_assets
+
+pytestmark = pytest.mark.gpu
+
+
+def _nif():
+    return nif_assets.synthetic_nif(), nif_assets.URBAN_ALLEY_META["max"], nif_assets.folded_mean()
+
+
+def test_empty_and_single_item_worklists(oracle, ptmi_lib):
+    r = ptmi_lib.Renderer(64, 64, max_work_items=128)
+    r.set_constant_env((1, 1, 1))
+    r.init_render_settings(samples_per_step=3)
+    empty = np.zeros(0, dtype=ptmi_lib.TRACE_DTYPE)
+    r.setup(empty)
+    r.path_trace()
+    st = r.read_results(empty)
+    assert st.paths == 0 and st.escaped == 0
+    one = np.zeros(1, dtype=ptmi_lib.TRACE_DTYPE)
+    one["u"], one["v"] = 31, 50
+    r.setup(one)
+    r.path_trace()
+    r.read_results(one)
+    ref = np.zeros(1, dtype=ptmi_lib.TRACE_DTYPE)
+    ref["u"], ref["v"] = 31, 50
+    oracle.render(oracle.make_config(width=64, height=64), None, ref, 0, 3)
+    assert one.tobytes() == ref.tobytes()
+    with pytest.raises(ptmi_lib.PtError):
+        r.setup(np.zeros(129, dtype=ptmi_lib.TRACE_DTYPE))     # larger than max_work_items
+    with pytest.raises(ptmi_lib.PtError):
+        r.read_results(np.zeros(2, dtype=ptmi_lib.TRACE_DTYPE))  # size differs from setup
+    r.close()
+
+
+@pytest.mark.parametrize("n", [63, 65, 255, 257, 4097])
+def test_ragged_worklist_sizes_with_padding_items(oracle, ptmi_lib, n):
+    """Sizes around wave / workgroup / chunk boundaries; includes (65535, 65535) padding and pre-loaded accumulators."""
+    W, H = 300, 200
+    rng = np.random.default_rng(n)
+    rec = np.zeros(n, dtype=ptmi_lib.TRACE_DTYPE)
+    rec["u"] = rng.integers(0, W, n)
+    rec["v"] = rng.integers(0, H, n)
+    rec["u"][::17] = 65535
+    rec["v"][::17] = 65535
+    rec["r"] = rng.random(n).astype(np.float32)           # accumulators carried in are kept and added to
+    rec["sampleCount"] = 2
+    rec["pathLength"] = 5
+    ref = rec.copy()
+    layers, mx, mean = _nif()
+    r = ptmi_lib.Renderer(W, H, max_work_items=n, max_path_length=7, iterations_per_batch=3)
+    r.init_nif_weights(layers, 12, mx, mean)
+    r.init_render_settings(samples_per_step=5)
+    r.setup(rec)
+    r.path_trace()
+    st = r.read_results(rec)
+    cfg = oracle.make_config(width=W, height=H, max_path_length=7, env_mode=oracle.ENV_NIF)
+    ost = oracle.render(cfg, oracle.Nif(layers, 12, mx, mean), ref, 0, 5)
+    assert (st.paths, st.segments, st.escaped) == (ost.paths, ost.segments, ost.escaped)
+    assert np.array_equal(rec["pathLength"], ref["pathLength"]) and np.array_equal(rec["sampleCount"], ref["sampleCount"])
+    for c in "rgb":
+        np.testing.assert_allclose(rec[c], ref[c], rtol=2e-2, atol=1e-6)
+    r.close()
+
+
+def test_nif_hot_swap_and_environment_switch(oracle, ptmi_lib):
+    """init_nif_weights may be called again (PathTracerApp.cpp:548-557); switching to a constant sky and back."""
+    W = H = 48
+    a = nif_assets.synthetic_nif(seed=1)
+    b = nif_assets.synthetic_nif(hidden=128, layer_count=4, seed=2)
+    mx, mean = nif_assets.URBAN_ALLEY_META["max"], nif_assets.folded_mean()
+    r = ptmi_lib.Renderer(W, H, max_path_length=5)
+    u = np.linspace(0.01, 0.99, 500, dtype=np.float32)
+    v = u[::-1].copy()
+    r.init_nif_weights(a, 12, mx, mean)
+    ya = r.nif_infer(u, v)
+    r.init_nif_weights(b, 12, mx, mean)
+    yb = r.nif_infer(u, v)
+    r.init_nif_weights(a, 12, mx, mean)
+    np.testing.assert_array_equal(r.nif_infer(u, v), ya)           # deterministic, state fully replaced
+    assert np.abs(ya - yb).max() > 1e-3
+    np.testing.assert_allclose(yb, oracle.Nif(b, 12, mx, mean).infer(u, v), rtol=2e-2)
+    r.set_constant_env((2, 2, 2))
+    r.init_render_settings(samples_per_step=2)
+    rec = ptmi_lib.worklist(W, H)
+    r.setup(rec)
+    r.path_trace()
+    r.read_results(rec)
+    assert rec["r"][0] == 4.0                                       # top-left pixel: sky, 2 samples x 2.0
+    r.close()
+
+
+def test_clear_accumulators_and_device_hdr_export(ptmi_lib):
+    import torch
+    W = H = 64
+    r = ptmi_lib.Renderer(W, H, max_path_length=6)
+    r.set_constant_env((1.0, 0.5, 0.25))
+    r.init_render_settings(samples_per_step=4)
+    rec = ptmi_lib.worklist(W, H)
+    r.setup(rec)
+    r.path_trace()
+    out = torch.zeros((rec.size, 3), dtype=torch.float32, device="cuda")
+    r.export_hdr_device(out.data_ptr(), rec.size)
+    r.synchronize()
+    r.read_results(rec)
+    exp = np.stack([rec["b"], rec["g"], rec["r"]], -1) * (np.float32(1.0) / rec["sampleCount"].astype(np.float32))[:, None]
+    np.testing.assert_array_equal(out.cpu().numpy(), exp)            # (b,g,r)/sampleCount as AccumulatedImage adds
+    r.clear_accumulators()                                         # LoadBalancer.cpp:198-213 on the device
+    r.read_results(rec)
+    assert np.all(rec["r"] == 0) and np.all(rec["sampleCount"] == 0) and np.all(rec["pathLength"] == 0)
+    assert rec["u"][5] == 5                                        # coordinates are kept
+    r.close()
+
+
+def test_two_handles_and_seed_semantics(ptmi_lib):
+    W = H = 40
+    rs = [ptmi_lib.Renderer(W, H, max_path_length=6) for _ in range(2)]
+    recs = []
+    for i, r in enumerate(rs):
+        r.set_constant_env((1, 1, 1))
+        r.init_render_settings(seed=1 + i, samples_per_step=4)
+        rec = ptmi_lib.worklist(W, H)
+        r.setup(rec)
+        recs.append(rec)
+    for r in rs:
+        r.path_trace()
+    for r, rec in zip(rs, recs):
+        r.read_results(rec)
+    assert recs[0].tobytes() != recs[1].tobytes()                   # different seeds, different samples
+    # same seed on the second handle reproduces the first exactly
+    rs[1].init_render_settings(seed=1, samples_per_step=4)
+    again = ptmi_lib.worklist(W, H)
+    rs[1].setup(again)
+    rs[1].path_trace()
+    rs[1].read_results(again)
+    assert again.tobytes() == recs[0].tobytes()
+    for r in rs:
+        r.close()
