@@ -340,16 +340,16 @@ bool launch_nif_diag(pt_handle h, const ptd::NifParams& N, int blocks) {
 
 template <int HID, int E>
 void launch_nif_t(pt_handle h, const ptd::NifParams& N, int blocks) {
-  // PTMI_NIF_VARIANT is an A/B switch for profiling: 1 = weights straight from L2 (v1),
-  // 2 = LDS ring, 4 waves x 64 samples, 3 = LDS ring, 8 waves x 32 samples, one tile per stage,
-  // default (4) = all layers through the ring, two tiles per stage.
-  static const int variant = getenv("PTMI_NIF_VARIANT") ? atoi(getenv("PTMI_NIF_VARIANT")) : 4;
 #ifdef PTMI_DIAG_BUILD
   if (launch_nif_diag<HID, E>(h, N, blocks)) return;
+  // A/B switch of the profiling build: 1 = weights straight from L2, 2 = LDS ring with 4 waves x 64 samples
+  static const int variant = getenv("PTMI_NIF_VARIANT") ? atoi(getenv("PTMI_NIF_VARIANT")) : 0;
+  if (variant == 1) { hipLaunchKernelGGL((ptd::nif_kernel<HID, E, 2>), dim3(blocks), dim3(256), 0, h->stream, N); return; }
+  if (variant == 2) { launch_nif_v2<HID, E, 2, 4>(h, N, blocks); return; }
+  if (variant == 3) { launch_nif_v2<HID, E, 1, 8>(h, N, blocks); return; }
 #endif
-  if (variant == 1) hipLaunchKernelGGL((ptd::nif_kernel<HID, E, 2>), dim3(blocks), dim3(256), 0, h->stream, N);
-  else if (variant == 2) launch_nif_v2<HID, E, 2, 4>(h, N, blocks);
-  else if (variant == 3 || N.n_layers > (uint32_t)ptd::NifV3Geometry<HID, E, 8, 2>::MAX_LAYERS) launch_nif_v2<HID, E, 1, 8>(h, N, blocks);
+  // v3 keeps the bias tiles of at most 8 layers resident in LDS; deeper networks take the v2 ring (layer 0 resident)
+  if (N.n_layers > (uint32_t)ptd::NifV3Geometry<HID, E, 8, 2>::MAX_LAYERS) launch_nif_v2<HID, E, 1, 8>(h, N, blocks);
   else launch_nif_v3<HID, E, 8, 2>(h, N, blocks);
 }
 

@@ -98,7 +98,7 @@ def test_render_backward_fold_matches_forward(oracle, ptmi_lib):
     r.close()
 
 
-@pytest.mark.parametrize("hidden,layers", [(64, 2), (128, 4), (320, 6), (512, 3), (1024, 8)])
+@pytest.mark.parametrize("hidden,layers", [(64, 2), (128, 4), (320, 6), (64, 10), (256, 9), (512, 3), (1024, 8)])
 def test_nif_infer_matches_oracle(oracle, ptmi_lib, hidden, layers):
     O = oracle
     L = nif_assets.synthetic_nif(hidden=hidden, layer_count=layers, seed=7 + hidden)
