@@ -1,49 +1,50 @@
-// One background thread with join: reference src/AsyncTask.hpp:14-67 (same interface and error behaviour).
+// Runs one host job at a time on a background thread while the device works on the next step.
+// Interface and error behaviour of the reference's AsyncTask (src/AsyncTask.hpp:14-67): run() throws
+// std::logic_error when a job is still pending, waitForCompletion() joins it, isRunning() reports progress.
 #pragma once
 #include <atomic>
 #include <functional>
-#include <memory>
 #include <stdexcept>
+#include <system_error>
 #include <thread>
+#include <utility>
 
 #include "logging.hpp"
 
 class AsyncTask {
 public:
-  AsyncTask() : running(false) {}
+  AsyncTask() = default;
+  AsyncTask(const AsyncTask&) = delete;
+  AsyncTask& operator=(const AsyncTask&) = delete;
   virtual ~AsyncTask() { waitForCompletion(); }
 
-  /// Run a function in a new thread.  Throws std::logic_error if a task is already in progress.
   void run(std::function<void()>&& f) {
-    if (job != nullptr) {
-      auto error = "Attempted to run AsyncTask while a job was in progress.";
-      pt_log::error_(error);
-      throw std::logic_error(error);
+    if (worker.joinable()) {
+      static const char* msg = "Attempted to run AsyncTask while a job was in progress.";
+      pt_log::error_(msg);
+      throw std::logic_error(msg);
     }
-    asyncFunc = std::move(f);
-    job.reset(new std::thread([this]() {
-      running = true;
-      asyncFunc();
-      running = false;
-    }));
+    task = std::move(f);
+    busy.store(true);
+    worker = std::thread([this] {
+      task();
+      busy.store(false);
+    });
   }
 
-  /// Wait for the job to complete.
   void waitForCompletion() {
-    if (job != nullptr) {
-      try {
-        job->join();
-        job.reset();
-      } catch (std::system_error&) {
-        pt_log::error_("Thread could not be joined.");
-      }
+    if (!worker.joinable()) return;
+    try {
+      worker.join();
+    } catch (const std::system_error&) {
+      pt_log::error_("Thread could not be joined.");
     }
   }
 
-  bool isRunning() const { return running; }
+  bool isRunning() const { return busy.load(); }
 
 private:
-  std::function<void()> asyncFunc;
-  std::unique_ptr<std::thread> job;
-  std::atomic<bool> running;
+  std::function<void()> task;
+  std::thread worker;
+  std::atomic<bool> busy{false};
 };

@@ -1,131 +1,96 @@
-// Reference: src/LoadBalancer.cpp.  Behaviour kept, including the quirks listed in SURVEY.md's appendix.
 #include "LoadBalancer.hpp"
 
 #include <algorithm>
 #include <cmath>
 #include <limits>
+#include <numeric>
 #include <random>
-#include <stdexcept>
 
 #include "logging.hpp"
 
-std::size_t calculateMaxRaysPerTile(std::size_t imageWidth, std::size_t imageHeight, const DeviceGeometry& target) {
-  const auto numTiles = target.getNumTiles();
-  const auto numWorkers = target.getNumWorkerContexts();
-  if ((imageWidth * imageHeight) % (numTiles * numWorkers)) {
-    pt_log::warn_("For best performance number of pixels in image should be divisible by {} x {} (tiles x workers).",
-                  numTiles, numWorkers);
+namespace {
+
+constexpr std::uint16_t kPaddingCoord = std::numeric_limits<std::uint16_t>::max();
+constexpr unsigned kShuffleSeed = 142u;   // LoadBalancer.cpp:133
+
+std::size_t resetAndSumPathLengths(RecordList& list) {
+  std::size_t total = 0;
+  const std::size_t n = list.size();
+#pragma omp parallel for reduction(+ : total) schedule(static)
+  for (std::size_t i = 0; i < n; ++i) {
+    total += list[i].pathLength;
+    list[i].clearAccumulators();
   }
-  const auto totalRayCount = imageWidth * imageHeight;
-  unsigned raysPerTile = std::ceil(totalRayCount / (float)numTiles);
-  raysPerTile += raysPerTile % numWorkers;  // sic: reference LoadBalancer.cpp:31
-  return std::max<std::size_t>(numWorkers, raysPerTile);
+  return total;
 }
 
-std::vector<TraceRecord> createWorkListForImage(std::size_t imageWidth, std::size_t imageHeight) {
-  std::vector<TraceRecord> workList;
-  workList.reserve(imageWidth * imageHeight);
-  for (std::size_t r = 0; r < imageHeight; ++r)
-    for (std::size_t c = 0; c < imageWidth; ++c) workList.emplace_back(c, r);
-  return workList;
+}  // namespace
+
+std::size_t calculateMaxRaysPerTile(std::size_t imageWidth, std::size_t imageHeight, const DeviceGeometry& target) {
+  const std::size_t tiles = target.getNumTiles(), workers = target.getNumWorkerContexts();
+  const std::size_t pixels = imageWidth * imageHeight;
+  if (pixels % (tiles * workers) != 0) {
+    pt_log::warn_("For best performance number of pixels in image should be divisible by {} x {} (tiles x workers).",
+                  tiles, workers);
+  }
+  unsigned rays = static_cast<unsigned>(std::ceil(pixels / static_cast<float>(tiles)));   // float division as the reference
+  rays += rays % workers;
+  return std::max<std::size_t>(workers, rays);
+}
+
+RecordList createWorkListForImage(std::size_t imageWidth, std::size_t imageHeight) {
+  RecordList items(imageWidth * imageHeight);
+  for (std::size_t i = 0; i < items.size(); ++i)
+    items[i] = TraceRecord(static_cast<std::uint16_t>(i % imageWidth), static_cast<std::uint16_t>(i / imageWidth));
+  return items;
 }
 
 std::vector<RecordList> createTracingJobs(std::size_t imageWidth, std::size_t imageHeight, const DeviceGeometry& target) {
-  const auto numTiles = target.getNumTiles();
-  const auto maxRaysPerTile = calculateMaxRaysPerTile(imageWidth, imageHeight, target);
-  auto paddedRayCount = maxRaysPerTile * numTiles;
-  auto workList = createWorkListForImage(imageWidth, imageHeight);
-  const auto dummyCoord = std::numeric_limits<std::uint16_t>::max();
-  while (workList.size() < paddedRayCount) workList.emplace_back(dummyCoord, dummyCoord);
-  auto copyItr = workList.cbegin();
-  std::vector<RecordList> perTileWork;
-  perTileWork.reserve(numTiles);
-  for (std::size_t t = 0; t < numTiles; ++t) {
-    perTileWork.emplace_back(maxRaysPerTile);
-    auto endItr = copyItr + maxRaysPerTile;
-    std::copy(copyItr, endItr, perTileWork.back().begin());
-    copyItr = endItr;
-  }
-  return perTileWork;
+  const std::size_t perJob = calculateMaxRaysPerTile(imageWidth, imageHeight, target);
+  const RecordList pixels = createWorkListForImage(imageWidth, imageHeight);
+  const TraceRecord padding(kPaddingCoord, kPaddingCoord);
+  std::vector<RecordList> jobs(target.getNumTiles(), RecordList(perJob, padding));
+  for (std::size_t i = 0; i < pixels.size(); ++i) jobs[i / perJob][i % perJob] = pixels[i];
+  return jobs;
 }
-
-WorkList::WorkList(std::size_t size) : activeWork(size), inactiveWork(size) {}
-WorkList::~WorkList() {}
-RecordList& WorkList::active() { return activeWork; }
-RecordList& WorkList::inactive() { return inactiveWork; }
-
-void WorkList::swap() {
-  std::swap(activeWork, inactiveWork);
-  if (activeWork.empty()) throw std::logic_error("The new active worklist is empty.");
-}
-
-LoadBalancer::LoadBalancer(std::size_t workItemCount) : work(workItemCount) {}
-LoadBalancer::~LoadBalancer() {}
 
 void LoadBalancer::randomiseWorkList(const std::vector<RecordList>& jobs) {
-  std::vector<TraceRecord> workList;
-  workList.reserve(jobs.size() * jobs.front().size());
-  for (const auto& j : jobs)
-    for (const auto& w : j) workList.push_back(w);
-  auto workSeed = 142u;
-  std::mt19937 g(workSeed);
-  std::shuffle(workList.begin(), workList.end(), g);
-  work.inactive() = workList;
+  RecordList flat;
+  flat.reserve(jobs.size() * jobs.front().size());
+  for (const RecordList& job : jobs) flat.insert(flat.end(), job.begin(), job.end());
+  std::mt19937 generator(kShuffleSeed);
+  std::shuffle(flat.begin(), flat.end(), generator);
+  work.inactive() = std::move(flat);
 }
 
 void LoadBalancer::allocateWorkByPathLength(const IpuJobList& jobs) {
-  auto sorted = work.inactive();
-  std::sort(sorted.begin(), sorted.end(),
-            [](const TraceRecord& a, const TraceRecord& b) -> bool { return a.pathLength < b.pathLength; });
-  std::vector<RecordList> perTileWork(jobs.size());
-  for (auto& t : perTileWork) t.reserve(jobs[0].getPixelCount());
-  auto shortItr = sorted.begin();
-  auto longItr = sorted.end() - 1;
-  pt_log::info_("Load balancing started ({} work items)", sorted.size());
-  pt_log::info_("Path length min/max: {}/{}", shortItr->pathLength, longItr->pathLength);
-  // Each job takes the shortest and the longest remaining path in turn (reference :168-181; like the
-  // reference this assumes an even item count per job).
-  while (true) {
-    for (auto& t : perTileWork) {
-      t.push_back(*shortItr);
-      t.push_back(*longItr);
-      ++shortItr;
-      --longItr;
+  RecordList& list = work.inactive();
+  RecordList byLength = list;
+  std::sort(byLength.begin(), byLength.end(),
+            [](const TraceRecord& a, const TraceRecord& b) { return a.pathLength < b.pathLength; });
+  pt_log::info_("Load balancing started ({} work items)", byLength.size());
+  pt_log::info_("Path length min/max: {}/{}", byLength.front().pathLength, byLength.back().pathLength);
+
+  // Deal (shortest, longest) pairs to the jobs in turn until the two ends of the sorted list meet.  Like the
+  // reference this visits every job in each round, so it expects an even item count per job.
+  const std::size_t nJobs = jobs.size();
+  std::vector<RecordList> dealt(nJobs);
+  for (RecordList& d : dealt) d.reserve(jobs.front().getPixelCount());
+  std::ptrdiff_t lo = 0, hi = static_cast<std::ptrdiff_t>(byLength.size()) - 1;
+  do {
+    for (std::size_t j = 0; j < nJobs; ++j) {
+      dealt[j].push_back(byLength[static_cast<std::size_t>(lo++)]);
+      dealt[j].push_back(byLength[static_cast<std::size_t>(hi--)]);
     }
-    if (longItr <= shortItr) break;
-  }
+  } while (hi > lo);
   pt_log::info_("Load balancing finished");
-  auto itr = sorted.begin();
-  for (auto& t : perTileWork)
-    for (auto& w : t) {
-      if (itr == sorted.end()) break;
-      *itr = w;
-      ++itr;
-    }
-  work.inactive() = sorted;
+
+  std::size_t out = 0;
+  for (const RecordList& d : dealt)
+    for (const TraceRecord& item : d)
+      if (out < list.size()) list[out++] = item;
 }
 
-std::size_t LoadBalancer::clearInactiveAccumulators() {
-  auto& list = work.inactive();
-  std::size_t sum = 0;
-#pragma omp parallel for reduction(+ : sum) schedule(static)
-  for (std::size_t i = 0; i < list.size(); ++i) {
-    auto& t = list[i];
-    sum += t.pathLength;
-    t.r = t.g = t.b = 0.f;
-    t.pathLength = 0;
-    t.sampleCount = 0;
-  }
-  return sum;
-}
+std::size_t LoadBalancer::clearInactiveAccumulators() { return resetAndSumPathLengths(work.inactive()); }
 
-void LoadBalancer::clearActiveAccumulators() {
-  auto& list = work.active();
-#pragma omp parallel for schedule(static)
-  for (std::size_t i = 0; i < list.size(); ++i) {
-    auto& t = list[i];
-    t.r = t.g = t.b = 0.f;
-    t.pathLength = 0;
-    t.sampleCount = 0;
-  }
-}
+void LoadBalancer::clearActiveAccumulators() { (void)resetAndSumPathLengths(work.active()); }

@@ -1,6 +1,10 @@
-// Host worklist management: reference src/LoadBalancer.hpp:14-56 (same free functions and classes).
+// Host-side worklist management with the reference's names and semantics (src/LoadBalancer.hpp, LoadBalancer.cpp):
+// padded per-job worklists, the seeded global shuffle, path-length balancing and the accumulator reset that also
+// returns the ray count.  poplar::Target is replaced by DeviceGeometry (IpuPathTraceJob.hpp).
 #pragma once
 #include <cstddef>
+#include <stdexcept>
+#include <utility>
 #include <vector>
 
 #include "IpuPathTraceJob.hpp"
@@ -8,36 +12,50 @@
 
 using RecordList = std::vector<TraceRecord>;
 
-/// LoadBalancer.cpp:14-36 (including its `r += r % workers` rounding, which is not a true round-up).
+/// Rays every job traces for one sample per pixel: ceil(pixels / tiles), then `+= r % workers` (the reference's
+/// rounding, LoadBalancer.cpp:27-35 -- deliberately not a round-up to a multiple), at least `workers`.
 std::size_t calculateMaxRaysPerTile(std::size_t imageWidth, std::size_t imageHeight, const DeviceGeometry& target);
-/// LoadBalancer.cpp:38-52: one item per pixel, row-major (c, r).
-std::vector<TraceRecord> createWorkListForImage(std::size_t imageWidth, std::size_t imageHeight);
-/// LoadBalancer.cpp:54-86: pad with (65535, 65535) items and cut into equal per-tile lists.
+
+/// One work item per pixel in row-major order (LoadBalancer.cpp:38-52).
+RecordList createWorkListForImage(std::size_t imageWidth, std::size_t imageHeight);
+
+/// Equal slices of the image worklist, one per job; the tail is padded with (65535, 65535) items that the film skips
+/// (LoadBalancer.cpp:54-86).
 std::vector<RecordList> createTracingJobs(std::size_t imageWidth, std::size_t imageHeight, const DeviceGeometry& target);
 
-/// A double buffered work list (LoadBalancer.cpp:88-108).
-struct WorkList {
-  WorkList(std::size_t size);
-  virtual ~WorkList();
-  void swap();
-  RecordList& active();
-  RecordList& inactive();
+/// Two equally sized record lists: the device owns `active()`, the host thread works on `inactive()`.
+class WorkList {
+public:
+  explicit WorkList(std::size_t size) : lists{RecordList(size), RecordList(size)} {}
+  virtual ~WorkList() = default;
+
+  RecordList& active() { return lists[0]; }
+  RecordList& inactive() { return lists[1]; }
+
+  /// Exchange the roles; an empty new active list is a logic error (LoadBalancer.cpp:103-108).
+  void swap() {
+    std::swap(lists[0], lists[1]);
+    if (lists[0].empty()) throw std::logic_error("The new active worklist is empty.");
+  }
 
 private:
-  RecordList activeWork;
-  RecordList inactiveWork;
+  RecordList lists[2];
 };
 
-struct LoadBalancer {
-  LoadBalancer(std::size_t workItemCount);
-  virtual ~LoadBalancer();
+class LoadBalancer {
+public:
+  explicit LoadBalancer(std::size_t workItemCount) : work(workItemCount) {}
+  virtual ~LoadBalancer() = default;
 
   WorkList& getWork() { return work; }
 
-  void randomiseWorkList(const std::vector<RecordList>& jobs);   // LoadBalancer.cpp:118-139
-  void allocateWorkByPathLength(const IpuJobList& jobs);         // LoadBalancer.cpp:141-192
-  std::size_t clearInactiveAccumulators();                       // LoadBalancer.cpp:198-213
-  void clearActiveAccumulators();                                // LoadBalancer.cpp:216-225
+  /// Flatten the jobs, shuffle with std::mt19937(142) and store as the inactive list (LoadBalancer.cpp:118-139).
+  void randomiseWorkList(const std::vector<RecordList>& jobs);
+  /// Re-deal the inactive list so every job gets shortest+longest path pairs (LoadBalancer.cpp:141-192).
+  void allocateWorkByPathLength(const IpuJobList& jobs);
+  /// Zero r,g,b,sampleCount,pathLength of the inactive list; returns the summed path lengths (LoadBalancer.cpp:198-213).
+  std::size_t clearInactiveAccumulators();
+  void clearActiveAccumulators();
 
 private:
   WorkList work;
