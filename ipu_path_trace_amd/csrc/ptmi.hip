@@ -450,7 +450,9 @@ int pt_create(const pt_config* cfg, pt_handle* out) {
   const uint32_t n = cfg->max_work_items;
   h->capacity = n;
   uint32_t k = cfg->iterations_per_batch;
-  if (k == 0) { k = (uint32_t)((8u << 20) / n); if (k < 1) k = 1; if (k > 32) k = 32; }
+  // auto: ~32 M paths per batch (2.5 GB of batch buffers at most -- small against 288 GB of HBM3E; larger batches
+  // mean fewer launch tails: 10 instead of 43 NIF launches per 300-spp step bought 2 %)
+  if (k == 0) { k = (uint32_t)((32u << 20) / n); if (k < 1) k = 1; if (k > 32) k = 32; }
   if ((uint64_t)k * n >= (1ull << 31)) k = (uint32_t)(((1ull << 31) - 1) / n);
   if (k == 0) { h->error = "max_work_items too large"; return bail(PT_ERR_INVALID_ARGUMENT); }
   h->iters_per_batch = k;
