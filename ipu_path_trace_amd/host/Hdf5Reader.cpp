@@ -1,0 +1,286 @@
+#include "Hdf5Reader.hpp"
+
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <stdexcept>
+
+namespace h5 {
+namespace {
+const unsigned char kSignature[8] = {0x89, 'H', 'D', 'F', '\r', '\n', 0x1a, '\n'};
+constexpr std::uint64_t kUndefined = ~0ull;
+[[noreturn]] void fail(const std::string& m) { throw std::runtime_error("HDF5 reader: " + m); }
+std::size_t pad8(std::size_t n) { return (n + 7) & ~std::size_t(7); }
+}  // namespace
+
+void File::need(std::size_t off, std::size_t n, const char* what) const {
+  if (off > d.size() || n > d.size() - off) fail(std::string("truncated file while reading ") + what);
+}
+
+std::uint64_t File::u(std::size_t off, int bytes) const {
+  need(off, bytes, "an integer");
+  std::uint64_t v = 0;
+  for (int i = bytes - 1; i >= 0; --i) v = (v << 8) | d[off + i];
+  if (bytes < 8 && v == ((1ull << (8 * bytes)) - 1) && bytes == sizeOffsets) return kUndefined;
+  return v;
+}
+
+File::File(const std::string& fileName) {
+  std::ifstream f(fileName, std::ios::binary);
+  if (!f) fail("could not open '" + fileName + "'");
+  d.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+  // the superblock sits at 0 or, behind a user block, at 512, 1024, 2048, ...
+  std::size_t sb = std::string::npos;
+  for (std::size_t off = 0; off + 8 <= d.size(); off = off ? off * 2 : 512) {
+    if (std::memcmp(&d[off], kSignature, 8) == 0) { sb = off; break; }
+  }
+  if (sb == std::string::npos) fail("'" + fileName + "' has no HDF5 signature");
+  const int version = d[sb + 8];
+  if (version > 1) fail("superblock version " + std::to_string(version) + " (written with a newer libver) is not supported");
+  sizeOffsets = d[sb + 13];
+  sizeLengths = d[sb + 14];
+  if ((sizeOffsets != 4 && sizeOffsets != 8) || (sizeLengths != 4 && sizeLengths != 8)) fail("unsupported offset/length size");
+  std::size_t p = sb + 24 + (version == 1 ? 4 : 0);
+  base = addr(p);
+  if (base == kUndefined) base = 0;
+  if (base != sb && base != 0) base = sb;   // addresses are relative to the superblock when a user block is present
+  if (base == 0 && sb != 0) base = sb;
+  p += 4 * sizeOffsets;                      // base, free-space, end-of-file, driver-info addresses
+  // root group symbol table entry: link name offset, object header address, cache type, reserved, scratch
+  rootHeader = addr(p + sizeOffsets);
+  if (rootHeader == kUndefined) fail("root group has no object header");
+}
+
+std::vector<File::Message> File::objectMessages(std::uint64_t headerAddress) const {
+  std::size_t p = (std::size_t)(base + headerAddress);
+  need(p, 16, "an object header");
+  if (d[p] != 1) {
+    if (std::memcmp(&d[p], "OHDR", 4) == 0) fail("version-2 object headers (libver='latest') are not supported");
+    fail("unexpected object header version " + std::to_string(d[p]));
+  }
+  const std::size_t total = u(p + 2, 2);
+  const std::size_t firstSize = u(p + 8, 4);
+  std::vector<Message> out;
+  std::vector<std::pair<std::size_t, std::size_t>> blocks{{p + 16, firstSize}};
+  for (std::size_t b = 0; b < blocks.size() && out.size() < total; ++b) {
+    std::size_t q = blocks[b].first, end = q + blocks[b].second;
+    need(q, blocks[b].second, "object header messages");
+    while (q + 8 <= end && out.size() < total) {
+      Message m{(std::uint16_t)u(q, 2), d[q + 4], q + 8, (std::size_t)u(q + 2, 2)};
+      need(m.offset, m.size, "a header message");
+      if (m.type == 0x0010) blocks.push_back({(std::size_t)(base + addr(m.offset)), (std::size_t)u(m.offset + sizeOffsets, sizeLengths)});
+      out.push_back(m);
+      q = m.offset + m.size;
+    }
+  }
+  return out;
+}
+
+void File::walkBtree(std::uint64_t node, std::uint64_t heapData, std::map<std::string, std::uint64_t>& out, int depth) const {
+  if (depth > 16) fail("group B-tree is too deep");
+  std::size_t p = (std::size_t)(base + node);
+  need(p, 24, "a B-tree node");
+  if (std::memcmp(&d[p], "TREE", 4) != 0) fail("bad B-tree node signature");
+  if (d[p + 4] != 0) fail("expected a group B-tree");
+  const int level = d[p + 5];
+  const std::size_t used = u(p + 6, 2);
+  std::size_t q = p + 8 + 2 * sizeOffsets;   // past the sibling pointers
+  for (std::size_t i = 0; i < used; ++i) {
+    q += sizeLengths;                       // key i
+    const std::uint64_t child = addr(q);
+    q += sizeOffsets;
+    if (level > 0) { walkBtree(child, heapData, out, depth + 1); continue; }
+    std::size_t s = (std::size_t)(base + child);
+    need(s, 8, "a symbol table node");
+    if (std::memcmp(&d[s], "SNOD", 4) != 0) fail("bad symbol table node signature");
+    const std::size_t n = u(s + 6, 2);
+    const std::size_t entry = 2 * sizeOffsets + 24;
+    for (std::size_t k = 0; k < n; ++k) {
+      std::size_t e = s + 8 + k * entry;
+      need(e, entry, "a symbol table entry");
+      const std::uint64_t nameOff = addr(e);
+      std::size_t np = (std::size_t)(base + heapData + nameOff);
+      need(np, 1, "a link name");
+      std::string name(reinterpret_cast<const char*>(&d[np]), strnlen(reinterpret_cast<const char*>(&d[np]), d.size() - np));
+      out[name] = addr(e + sizeOffsets);
+    }
+  }
+}
+
+std::map<std::string, std::uint64_t> File::groupLinks(std::uint64_t headerAddress) const {
+  std::map<std::string, std::uint64_t> out;
+  bool found = false;
+  for (const Message& m : objectMessages(headerAddress)) {
+    if (m.type == 0x0002 || m.type == 0x0006) fail("new-style groups (link messages) are not supported");
+    if (m.type != 0x0011) continue;
+    found = true;
+    const std::uint64_t btree = addr(m.offset), heap = addr(m.offset + sizeOffsets);
+    std::size_t hp = (std::size_t)(base + heap);
+    need(hp, 8 + 2 * sizeLengths + sizeOffsets, "a local heap");
+    if (std::memcmp(&d[hp], "HEAP", 4) != 0) fail("bad local heap signature");
+    const std::uint64_t heapData = addr(hp + 8 + 2 * sizeLengths);
+    walkBtree(btree, heapData, out, 0);
+  }
+  if (!found) fail("object is not a group");
+  return out;
+}
+
+std::uint64_t File::resolve(const std::string& path) const {
+  std::uint64_t cur = rootHeader;
+  std::stringstream ss(path);
+  std::string part;
+  while (std::getline(ss, part, '/')) {
+    if (part.empty()) continue;
+    auto links = groupLinks(cur);
+    auto it = links.find(part);
+    if (it == links.end()) fail("no object '" + part + "' on path '" + path + "'");
+    cur = it->second;
+  }
+  return cur;
+}
+
+bool File::exists(const std::string& path) const {
+  try { (void)resolve(path); return true; } catch (const std::runtime_error&) { return false; }
+}
+
+std::vector<std::string> File::listGroup(const std::string& groupPath) const {
+  std::vector<std::string> names;
+  for (auto& kv : groupLinks(resolve(groupPath))) names.push_back(kv.first);
+  return names;
+}
+
+std::map<std::string, File::Attribute> File::attributes(std::uint64_t headerAddress) const {
+  std::map<std::string, Attribute> out;
+  for (const Message& m : objectMessages(headerAddress)) {
+    if (m.type != 0x000C) continue;
+    const std::size_t p = m.offset;
+    const int version = d[p];
+    if (version < 1 || version > 3) fail("unsupported attribute message version");
+    const std::size_t nameSize = u(p + 2, 2), dtSize = u(p + 4, 2), dsSize = u(p + 6, 2);
+    std::size_t q = p + 8 + (version == 3 ? 1 : 0);
+    auto step = [&](std::size_t n) { std::size_t at = q; q += (version == 1) ? pad8(n) : n; return at; };
+    const std::size_t nameAt = step(nameSize), dtAt = step(dtSize), dsAt = step(dsSize);
+    need(nameAt, nameSize, "an attribute name");
+    std::string name(reinterpret_cast<const char*>(&d[nameAt]), strnlen(reinterpret_cast<const char*>(&d[nameAt]), nameSize));
+    Attribute a;
+    a.datatype.assign(d.begin() + dtAt, d.begin() + dtAt + dtSize);
+    a.dataspace.assign(d.begin() + dsAt, d.begin() + dsAt + dsSize);
+    if (q > m.offset + m.size) fail("attribute message overruns its header message");
+    a.data.assign(d.begin() + q, d.begin() + m.offset + m.size);
+    out[name] = std::move(a);
+  }
+  return out;
+}
+
+bool File::hasAttribute(const std::string& objectPath, const std::string& name) const {
+  return attributes(resolve(objectPath)).count(name) != 0;
+}
+
+std::string File::globalHeapObject(std::uint64_t collection, std::uint32_t index) const {
+  std::size_t p = (std::size_t)(base + collection);
+  need(p, 8 + sizeLengths, "a global heap collection");
+  if (std::memcmp(&d[p], "GCOL", 4) != 0) fail("bad global heap signature");
+  const std::size_t size = u(p + 8, sizeLengths);
+  std::size_t q = p + 8 + sizeLengths, end = p + size;
+  while (q + 8 + sizeLengths <= end) {
+    const std::uint32_t idx = (std::uint32_t)u(q, 2);
+    const std::size_t osize = u(q + 8, sizeLengths);
+    if (idx == 0) break;   // free space
+    if (idx == index) {
+      need(q + 8 + sizeLengths, osize, "a global heap object");
+      return std::string(reinterpret_cast<const char*>(&d[q + 8 + sizeLengths]), osize);
+    }
+    q += 8 + sizeLengths + pad8(osize);
+  }
+  fail("global heap object not found");
+}
+
+std::string File::readStringAttribute(const std::string& objectPath, const std::string& name) const {
+  auto attrs = attributes(resolve(objectPath));
+  auto it = attrs.find(name);
+  if (it == attrs.end()) fail("no attribute '" + name + "' on '" + objectPath + "'");
+  const Attribute& a = it->second;
+  if (a.datatype.size() < 8) fail("malformed attribute datatype");
+  const int cls = a.datatype[0] & 0x0f;
+  std::uint32_t tsize;
+  std::memcpy(&tsize, &a.datatype[4], 4);
+  if (cls == 3) {   // fixed-length string, null terminated or padded
+    if (a.data.size() < tsize) fail("attribute data shorter than its string type");
+    return std::string(reinterpret_cast<const char*>(a.data.data()), strnlen(reinterpret_cast<const char*>(a.data.data()), tsize));
+  }
+  if (cls == 9 && (a.datatype[1] & 0x0f) == 1) {   // variable-length string: {length, collection address, index}
+    if (a.data.size() < 4u + sizeOffsets + 4u) fail("malformed variable-length string attribute");
+    std::uint32_t len, idx;
+    std::memcpy(&len, &a.data[0], 4);
+    std::uint64_t coll = 0;
+    for (int i = sizeOffsets - 1; i >= 0; --i) coll = (coll << 8) | a.data[4 + i];
+    std::memcpy(&idx, &a.data[4 + sizeOffsets], 4);
+    std::string s = globalHeapObject(coll, idx);
+    if (s.size() > len) s.resize(len);
+    return s;
+  }
+  fail("attribute '" + name + "' is not a string");
+}
+
+Dataset File::openDataSet(const std::string& path) const {
+  Dataset out;
+  bool haveSpace = false, haveType = false, haveLayout = false;
+  for (const Message& m : objectMessages(resolve(path))) {
+    const std::size_t p = m.offset;
+    if (m.type == 0x0001) {   // dataspace
+      const int version = d[p], rank = d[p + 1];
+      std::size_t q;
+      if (version == 1) q = p + 8;
+      else if (version == 2) q = p + 4;
+      else fail("unsupported dataspace version");
+      for (int i = 0; i < rank; ++i) out.shape.push_back((std::size_t)u(q + i * sizeLengths, sizeLengths));
+      haveSpace = true;
+    } else if (m.type == 0x0003) {   // datatype
+      const int cls = d[p] & 0x0f;
+      out.isFloat = (cls == 1);
+      out.elementSize = (std::size_t)u(p + 4, 4);
+      if (cls == 1 && (d[p + 1] & 1)) fail("big-endian floating point data is not supported");
+      haveType = true;
+    } else if (m.type == 0x0008) {   // data layout
+      const int version = d[p];
+      if (version == 3) {
+        const int cls = d[p + 1];
+        if (cls == 1) {
+          const std::uint64_t a = addr(p + 2);
+          const std::size_t n = u(p + 2 + sizeOffsets, sizeLengths);
+          if (a != kUndefined) { need((std::size_t)(base + a), n, "dataset data"); out.bytes.assign(d.begin() + base + a, d.begin() + base + a + n); }
+        } else if (cls == 0) {
+          const std::size_t n = u(p + 2, 2);
+          need(p + 4, n, "compact dataset data");
+          out.bytes.assign(d.begin() + p + 4, d.begin() + p + 4 + n);
+        } else fail("chunked datasets are not supported (" + path + ")");
+      } else if (version == 1 || version == 2) {
+        const int rank = d[p + 1], cls = d[p + 2];
+        std::size_t q = p + 8;
+        if (cls == 1) {
+          const std::uint64_t a = addr(q);
+          q += sizeOffsets;
+          std::size_t n = 1;
+          for (int i = 0; i < rank; ++i) n *= (std::size_t)u(q + 4 * i, 4);   // last dimension is the element size
+          if (a != kUndefined) { need((std::size_t)(base + a), n, "dataset data"); out.bytes.assign(d.begin() + base + a, d.begin() + base + a + n); }
+        } else if (cls == 0) {
+          q += 4 * rank;
+          const std::size_t n = u(q, 4);
+          need(q + 4, n, "compact dataset data");
+          out.bytes.assign(d.begin() + q + 4, d.begin() + q + 4 + n);
+        } else fail("chunked datasets are not supported (" + path + ")");
+      } else fail("unsupported data layout version");
+      haveLayout = true;
+    } else if (m.type == 0x000B) {
+      fail("filtered (compressed) datasets are not supported (" + path + ")");
+    }
+  }
+  if (!haveSpace || !haveType || !haveLayout) fail("'" + path + "' is not a dataset");
+  std::size_t n = out.elementSize;
+  for (auto s : out.shape) n *= s;
+  if (out.bytes.size() < n) fail("dataset '" + path + "' holds fewer bytes than its shape needs");
+  out.bytes.resize(n);
+  return out;
+}
+
+}  // namespace h5

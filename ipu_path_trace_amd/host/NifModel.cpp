@@ -7,6 +7,7 @@
 #include <sstream>
 #include <stdexcept>
 
+#include "Hdf5Model.hpp"
 #include "json.hpp"
 #include "logging.hpp"
 
@@ -75,6 +76,21 @@ NifModel::Data::Data(const std::string& weightFile, const std::string& metaFile)
 // converted.ptnif: "PTNIF1\0\0", u32 n_layers, u32 embedding_dim, then per layer
 // u32 rows, cols, dtype (0 = float16), relu, has_bias followed by the kernel bytes [rows][cols] and bias bytes.
 void NifModel::Data::setupModel(const std::string& weightFile) {
+  if (weightFile.size() > 5 && (weightFile.rfind(".hdf5") == weightFile.size() - 5 || weightFile.rfind(".h5") == weightFile.size() - 3)) {
+    // the reference's own asset format: NifModel.cpp:51-85 on top of Hdf5Model
+    Hdf5Model h5model(weightFile);
+    std::size_t i = 0;
+    for (const auto& l : h5model.get()) {
+      layers.emplace_back(l.kernelData.shape, l.kernelData.isHalf() ? "float16" : "float32", l.activation, l.name);
+      auto& newLayer = layers.back();
+      newLayer.kernel.data = l.kernelData.storage;
+      if (l.useBias) newLayer.bias.data = l.biasData.storage;
+      if (newLayer.activationFunction == "linear") newLayer.activationFunction = "none";   // NifModel.cpp:73-76
+      pt_log::debug_("Layer {}: weight tensors: {} ({} x {})", i, newLayer.kernel.getName(), l.kernelData.shape[0], l.kernelData.shape[1]);
+      i += 1;
+    }
+    return;
+  }
   std::ifstream f(weightFile, std::ios::binary);
   if (!f) throw std::runtime_error("Could not open NIF weight file '" + weightFile + "'");
   char magic[8];

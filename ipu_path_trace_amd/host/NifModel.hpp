@@ -54,8 +54,8 @@ struct DenseLayer {
 struct NifModel {
   /// Container for all NIF data (shared between devices): NifModel.hpp:21-37.
   struct Data {
-    /// `weightFile`: the reference reads <assets>/converted.hdf5 with libhdf5 (Hdf5Model.cpp:62-87); this
-    /// build has no HDF5 library and reads the flat side-car <assets>/converted.ptnif instead
+    /// `weightFile`: <assets>/converted.hdf5 as the reference reads it (Hdf5Model.cpp:62-87; here through the
+    /// dependency-free reader of Hdf5Reader.hpp), or the flat side-car <assets>/converted.ptnif
     /// (ipu_path_trace_amd/nif_assets.py: write_ptnif documents the format).
     Data(const std::string& weightFile, const std::string& metaFile);
     /// Seeded stand-in weights of the architecture named by the metadata (the trained weights are not

@@ -98,16 +98,18 @@ void PathTracerApp::init(const OptionMap& options) {
 bool PathTracerApp::loadNifModels(std::size_t numDevices, const std::string& assetPath) {
   try {
     const auto metaFile = assetPath + "/nif_metadata.txt";
-    const auto weightFile = assetPath + "/converted.ptnif";
+    const auto h5File = assetPath + "/converted.hdf5";          // the reference's asset (PathTracerApp.cpp:110)
+    const auto weightFile = assetPath + "/converted.ptnif";      // flat side-car written by nif_assets.write_ptnif
     std::shared_ptr<NifModel::Data> nifData;
-    if (std::ifstream(weightFile).good()) {
+    if (std::ifstream(h5File).good()) {
+      nifData = std::make_shared<NifModel::Data>(h5File, metaFile);
+    } else if (std::ifstream(weightFile).good()) {
       nifData = std::make_shared<NifModel::Data>(weightFile, metaFile);
     } else if (args.flag("synthetic-nif")) {
       pt_log::warn_("'{}' not found: using seeded synthetic NIF weights", weightFile);
       nifData = NifModel::Data::synthetic(metaFile, 2024u);
     } else {
-      throw std::runtime_error("'" + weightFile + "' not found (convert the Keras converted.hdf5 with "
-                               "tools/hdf5_to_ptnif.py, or pass --synthetic-nif)");
+      throw std::runtime_error("neither '" + h5File + "' nor '" + weightFile + "' found (pass --synthetic-nif for stand-in weights)");
     }
     models.clear();
     for (std::size_t c = 0; c < numDevices; ++c)

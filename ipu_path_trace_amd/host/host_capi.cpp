@@ -1,4 +1,5 @@
 // extern "C" test shim over the host classes (for the Python test-suite; not part of the product boundary).
+#include <cstdio>
 #include <cstring>
 #include <string>
 
@@ -79,3 +80,64 @@ int pth_read_metadata(const char* file, double* out8) {
 std::size_t pth_round_samples(std::size_t spp, std::size_t per_step) { return roundSamplesPerPixel(spp, per_step); }
 
 }  // extern "C"
+
+// ---- HDF5 reader shim (tests)
+#include "Hdf5Reader.hpp"
+extern "C" {
+// Writes a '\n'-joined listing "name" per link of `group` into out; returns the count or -1 (message in out).
+int pth_h5_list(const char* file, const char* group, char* out, std::size_t cap) {
+  try {
+    h5::File f(file);
+    std::string s;
+    auto names = f.listGroup(group);
+    for (auto& n : names) s += n + "\n";
+    std::snprintf(out, cap, "%s", s.c_str());
+    return (int)names.size();
+  } catch (const std::exception& e) { std::snprintf(out, cap, "%s", e.what()); return -1; }
+}
+int pth_h5_attr(const char* file, const char* object, const char* name, char* out, std::size_t cap) {
+  try {
+    h5::File f(file);
+    std::string s = f.readStringAttribute(object, name);
+    if (s.size() + 1 > cap) return -2;
+    std::memcpy(out, s.data(), s.size());
+    out[s.size()] = 0;
+    return (int)s.size();
+  } catch (const std::exception& e) { std::snprintf(out, cap, "%s", e.what()); return -1; }
+}
+// shape into dims[0..7] (rank returned), element size and raw bytes
+int pth_h5_dataset(const char* file, const char* path, std::size_t* dims, std::size_t* elem, unsigned char* bytes, std::size_t cap,
+                   char* err, std::size_t errcap) {
+  try {
+    h5::File f(file);
+    h5::Dataset ds = f.openDataSet(path);
+    for (std::size_t i = 0; i < ds.shape.size() && i < 8; ++i) dims[i] = ds.shape[i];
+    *elem = ds.elementSize;
+    if (bytes && cap >= ds.bytes.size()) std::memcpy(bytes, ds.bytes.data(), ds.bytes.size());
+    return (int)ds.shape.size();
+  } catch (const std::exception& e) { std::snprintf(err, errcap, "%s", e.what()); return -1; }
+}
+}
+
+#include "Hdf5Model.hpp"
+extern "C" {
+// Loads a Keras H5 through Hdf5Model exactly as NifModel::Data::setupModel does; per layer writes
+// {rows, cols, is_half, relu, has_bias, sum of the kernel's 16-bit words} into out; returns the layer count.
+int pth_h5_model(const char* file, unsigned long long* out, std::size_t cap, char* err, std::size_t errcap) {
+  try {
+    Hdf5Model m(file);
+    std::size_t i = 0;
+    for (const auto& l : m.get()) {
+      if (6 * (i + 1) > cap) break;
+      unsigned long long sum = 0;
+      const auto* w = reinterpret_cast<const std::uint16_t*>(l.kernelData.storage.data());
+      for (std::size_t k = 0; k < l.kernelData.storage.size() / 2; ++k) sum += w[k];
+      out[6 * i + 0] = l.kernelData.shape[0]; out[6 * i + 1] = l.kernelData.shape[1];
+      out[6 * i + 2] = l.kernelData.isHalf(); out[6 * i + 3] = l.activation == "relu";
+      out[6 * i + 4] = l.useBias; out[6 * i + 5] = sum;
+      ++i;
+    }
+    return (int)i;
+  } catch (const std::exception& e) { std::snprintf(err, errcap, "%s", e.what()); return -1; }
+}
+}

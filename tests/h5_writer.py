@@ -1,0 +1,172 @@
+"""Minimal HDF5 writer for test files (classic structures only: superblock v0, version-1 object headers, symbol-table
+groups with v1 B-tree / SNOD / local heap, contiguous datasets, fixed- and variable-length string attributes).
+
+Test infrastructure: it produces Keras-shaped `converted.hdf5` files for the dependency-free reader in
+ipu_path_trace_amd/host/Hdf5Reader.cpp (there is no h5py here).  The reader is additionally checked against a file
+written by the real HDF5 library (scipy's MATLAB v7.3 fixture), see tests/test_hdf5.py.
+"""
+import struct
+
+import numpy as np
+
+UNDEF = 0xFFFFFFFFFFFFFFFF
+
+
+def _pad8(b):
+    return b + b"\0" * ((-len(b)) % 8)
+
+
+class H5Writer:
+    def __init__(self, user_block=0, snod_capacity=8):
+        self.buf = bytearray(b"\0" * user_block)
+        self.base = user_block
+        self.snod_capacity = snod_capacity
+        self.sb_at = len(self.buf)
+        self.buf += b"\0" * 96                      # superblock placeholder (24 + 4*8 + 40 = 96)
+        self.gheap = []                              # (index, bytes) of variable-length strings
+        self.gheap_addr = None
+
+    # ---- low level
+    def _alloc(self, data):
+        self.buf += b"\0" * ((-len(self.buf)) % 8)
+        at = len(self.buf) - self.base
+        self.buf += data
+        return at
+
+    def _patch(self, at, data):
+        self.buf[self.base + at: self.base + at + len(data)] = data
+
+    @staticmethod
+    def _msg(mtype, data, flags=0):
+        data = _pad8(data)
+        return struct.pack("<HHB3x", mtype, len(data), flags) + data
+
+    def _object_header(self, messages):
+        body = b"".join(messages)
+        return self._alloc(struct.pack("<BBHII4x", 1, 0, len(messages), 1, len(body)) + body)
+
+    # ---- messages
+    @staticmethod
+    def _dataspace(shape):
+        return struct.pack("<BBB5x", 1, len(shape), 0) + b"".join(struct.pack("<Q", s) for s in shape)
+
+    @staticmethod
+    def _float_type(size):
+        sign, exploc, expsize, mansize, bias = {2: (15, 10, 5, 10, 15), 4: (31, 23, 8, 23, 127), 8: (63, 52, 11, 52, 1023)}[size]
+        return struct.pack("<BBBBI", 0x11, 0x20, sign, 0, size) + struct.pack("<HHBBBBI", 0, 8 * size, exploc, expsize, 0, mansize, bias)
+
+    @staticmethod
+    def _string_type(n):
+        return struct.pack("<BBBBI", 0x13, 0x00, 0, 0, n)       # class 3, null-terminated, ASCII
+
+    def _attribute(self, name, value, vlen=False):
+        nm = name.encode() + b"\0"
+        val = value.encode() if isinstance(value, str) else value
+        if vlen:
+            idx = len(self.gheap) + 1
+            self.gheap.append((idx, val))
+            dt = struct.pack("<BBBBI", 0x19, 0x01, 0, 0, 16) + self._string_type(1)   # vlen of 1-byte strings
+            data = struct.pack("<IQI", len(val), 0, idx)                                # collection address patched later
+            self._vlen_refs = getattr(self, "_vlen_refs", [])
+        else:
+            dt = self._string_type(len(val) + 1)
+            data = val + b"\0"
+        ds = struct.pack("<BBB5x", 1, 0, 0)                      # scalar
+        body = struct.pack("<BBHHH", 1, 0, len(nm), len(dt), len(ds)) + _pad8(nm) + _pad8(dt) + _pad8(ds) + data
+        return self._msg(0x000C, body), (len(struct.pack("<BBHHH", 1, 0, 0, 0, 0)) + len(_pad8(nm)) + len(_pad8(dt)) + len(_pad8(ds)) + 4 if vlen else None)
+
+    # ---- objects
+    def dataset(self, array, attrs=None):
+        a = np.ascontiguousarray(array)
+        raw = self._alloc(a.tobytes())
+        msgs = [self._msg(0x0001, self._dataspace(a.shape)), self._msg(0x0003, self._float_type(a.dtype.itemsize), flags=1),
+                self._msg(0x0008, struct.pack("<BBQQ", 3, 1, raw, a.nbytes))]
+        return self._finish_object(msgs, attrs)
+
+    def _finish_object(self, msgs, attrs):
+        fixups = []
+        for name, value in (attrs or {}).items():
+            vlen = isinstance(value, tuple)
+            m, off = self._attribute(name, value[0] if vlen else value, vlen=vlen)
+            if vlen:
+                fixups.append((sum(len(x) for x in msgs) + 8 + off, None))
+            msgs.append(m)
+        at = self._object_header(msgs)
+        for off, _ in fixups:
+            self._pending = getattr(self, "_pending", [])
+            self._pending.append(at + 16 + off)     # position of the 8-byte collection address inside the header
+        return at
+
+    def group(self, children, attrs=None):
+        """children: dict name -> object header address."""
+        names = sorted(children)
+        heap_data = bytearray(b"\0" * 8)
+        offsets = {}
+        for n in names:
+            offsets[n] = len(heap_data)
+            heap_data += _pad8(n.encode() + b"\0")
+        data_at = self._alloc(bytes(heap_data))
+        heap_at = self._alloc(b"HEAP" + struct.pack("<B3xQQQ", 0, len(heap_data), UNDEF, data_at))
+        # symbol table nodes of at most snod_capacity entries, one B-tree leaf level
+        snods = []
+        for i in range(0, max(len(names), 1), self.snod_capacity):
+            part = names[i:i + self.snod_capacity]
+            body = b"SNOD" + struct.pack("<BBH", 1, 0, len(part))
+            for n in part:
+                body += struct.pack("<QQII16x", offsets[n], children[n], 0, 0)
+            snods.append((self._alloc(body), offsets[part[-1]] if part else 0))
+        tree = b"TREE" + struct.pack("<BBHQQ", 0, 0, len(snods), UNDEF, UNDEF) + struct.pack("<Q", 0)
+        for at, last_key in snods:
+            tree += struct.pack("<QQ", at, last_key)
+        tree_at = self._alloc(tree)
+        msgs = [self._msg(0x0011, struct.pack("<QQ", tree_at, heap_at))]
+        at = self._finish_object(msgs, attrs)
+        self._last_group = (tree_at, heap_at)
+        return at
+
+    def finish(self, root_header):
+        tree_at, heap_at = self._last_group
+        if self.gheap:
+            body = b""
+            for idx, val in self.gheap:
+                body += struct.pack("<HH4xQ", idx, 1, len(val)) + _pad8(val)
+            body += struct.pack("<HH4xQ", 0, 0, 0)
+            size = 16 + len(body)
+            self.gheap_addr = self._alloc(b"GCOL" + struct.pack("<B3xQ", 1, size) + body)
+            for pos in getattr(self, "_pending", []):
+                self._patch(pos, struct.pack("<Q", self.gheap_addr))
+        eof = len(self.buf) - self.base
+        sb = b"\x89HDF\r\n\x1a\n" + struct.pack("<BBBBBBBBHHI", 0, 0, 0, 0, 0, 8, 8, 0, 4, 16, 0)
+        sb += struct.pack("<QQQQ", 0 if self.base == 0 else self.base, UNDEF, eof, UNDEF)
+        sb += struct.pack("<QQII", 0, root_header, 1, 0) + struct.pack("<QQ", tree_at, heap_at)
+        assert len(sb) == 96
+        self.buf[self.sb_at:self.sb_at + 96] = sb
+        return bytes(self.buf)
+
+
+def write_keras_h5(path, layers, vlen_config=False, user_block=0, snod_capacity=8, with_concat=True):
+    """Keras "Functional" H5 of a NIF: layers = [(kernel [in,out], bias | None, relu)], dataset paths
+    /model_weights/<name>/<name>/{kernel:0,bias:0} (reference src/keras/Hdf5Model.cpp:71-82)."""
+    import json
+    w = H5Writer(user_block=user_block, snod_capacity=snod_capacity)
+    names = ["dense" if i == 0 else "dense_%d" % i for i in range(len(layers))]
+    cfg_layers = [{"class_name": "InputLayer", "config": {"name": "input_1", "dtype": "float32"}}]
+    layer_groups = {}
+    for name, (k, b, relu) in zip(names, layers):
+        if with_concat and k.shape[0] not in (layers[0][0].shape[0], layers[0][0].shape[1]):
+            cfg_layers.append({"class_name": "Concatenate", "config": {"name": "concatenate", "axis": -1}})
+        dt = {"float16": "float16", "float32": "float32"}[str(k.dtype)]
+        cfg_layers.append({"class_name": "Dense", "config": {"name": name, "dtype": dt, "units": int(k.shape[1]),
+                                                              "activation": "relu" if relu else "linear",
+                                                              "use_bias": b is not None}})
+        inner = {"kernel:0": w.dataset(k)}
+        if b is not None:
+            inner["bias:0"] = w.dataset(b)
+        layer_groups[name] = w.group({name: w.group(inner)}, attrs={"weight_names": name})
+    config = json.dumps({"class_name": "Functional", "config": {"name": "model", "layers": cfg_layers}})
+    weights = w.group(layer_groups, attrs={"backend": "tensorflow", "keras_version": "2.8.0"})
+    root = w.group({"model_weights": weights},
+                   attrs={"keras_version": "2.8.0", "backend": "tensorflow",
+                          "model_config": (config,) if vlen_config else config})
+    with open(path, "wb") as f:
+        f.write(w.finish(root))

@@ -1,0 +1,116 @@
+"""the NIF asset loader (Keras H5 -> Dense layers) without libhdf5."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from ipu_path_trace_amd import nif_assets
+from tests.h5_writer import write_keras_h5
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "ipu_path_trace_amd", "host")
+REAL = "/usr/local/lib/python3.10/dist-packages/scipy/io/matlab/tests/data/testhdf5_7.4_GLNX86.mat"
+
+
+@pytest.fixture(scope="module")
+def host():
+    subprocess.check_call(["make", "-C", HOST, "-s"])
+    L = C.CDLL(os.path.join(HOST, "libpthost.so"))
+    st = C.c_size_t
+    L.pth_h5_list.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, st]
+    L.pth_h5_attr.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, st]
+    L.pth_h5_dataset.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, st, C.c_char_p, st]
+    L.pth_h5_model.argtypes = [C.c_char_p, C.c_void_p, st, C.c_char_p, st]
+    return L
+
+
+def _dataset(L, f, path, cap=1 << 22):
+    dims, el = (C.c_size_t * 8)(), C.c_size_t()
+    raw, err = np.zeros(cap, np.uint8), C.create_string_buffer(512)
+    r = L.pth_h5_dataset(f.encode(), path.encode(), dims, C.byref(el), raw.ctypes.data, cap, err, 512)
+    if r < 0:
+        raise RuntimeError(err.value.decode())
+    shape = tuple(dims[:r])
+    return shape, el.value, raw[: int(np.prod(shape)) * el.value]
+
+
+@pytest.mark.skipif(not os.path.exists(REAL), reason="scipy's MATLAB v7.3 fixture is not installed")
+def test_reader_on_a_file_written_by_the_real_hdf5_library(host):
+    """MATLAB v7.3 = HDF5 behind a 512-byte user block, old-style group, contiguous float64 dataset, string attribute."""
+    buf = C.create_string_buffer(4096)
+    assert host.pth_h5_list(REAL.encode(), b"/", buf, 4096) == 1 and buf.value == b"testdouble\n"
+    shape, el, raw = _dataset(host, REAL, "/testdouble")
+    assert shape == (9, 1) and el == 8
+    np.testing.assert_allclose(raw.view(np.float64), np.linspace(0, 2 * np.pi, 9), rtol=1e-15)
+    assert host.pth_h5_attr(REAL.encode(), b"/testdouble", b"MATLAB_class", buf, 4096) == 6 and buf.value == b"double"
+
+
+@pytest.mark.parametrize("vlen,user_block,cap", [(False, 0, 8), (True, 0, 8), (False, 512, 3)])
+def test_keras_h5_roundtrip(host, tmp_path, vlen, user_block, cap):
+    """A Keras-shaped converted.hdf5 (fixed- or variable-length model_config, multi-node group B-tree) loads into the
+    same Dense layers: names, shapes, activations, raw fp16 bytes."""
+    layers = nif_assets.synthetic_nif(hidden=64, layer_count=6, seed=3)
+    layers[2] = (layers[2][0], None, True)                       # one layer without a bias
+    p = str(tmp_path / "converted.hdf5")
+    write_keras_h5(p, layers, vlen_config=vlen, user_block=user_block, snod_capacity=cap)
+    buf = C.create_string_buffer(1 << 16)
+    assert host.pth_h5_list(p.encode(), b"/model_weights", buf, 1 << 16) == 7
+    assert buf.value.decode().split() == sorted("dense" if i == 0 else "dense_%d" % i for i in range(7))
+    assert host.pth_h5_attr(p.encode(), b"/", b"keras_version", buf, 1 << 16) > 0 and buf.value == b"2.8.0"
+    n = host.pth_h5_attr(p.encode(), b"/", b"model_config", buf, 1 << 16)
+    assert n > 100 and b'"Functional"' in buf.value
+    shape, el, raw = _dataset(host, p, "/model_weights/dense_3/dense_3/kernel:0")
+    assert shape == layers[3][0].shape and el == 2 and raw.tobytes() == layers[3][0].tobytes()
+    # through Hdf5Model + NifModel::Data::setupModel: summary "name rows cols half relu bias sha..." per layer
+    out = np.zeros(64, np.uint64)
+    err = C.create_string_buffer(512)
+    nl = host.pth_h5_model(p.encode(), out.ctypes.data, out.size, err, 512)
+    assert nl == 7, err.value
+    for i, (k, b, relu) in enumerate(layers):
+        rows, cols, half, is_relu, has_bias, ksum = [int(v) for v in out[6 * i: 6 * i + 6]]
+        assert (rows, cols) == k.shape and half == 1 and is_relu == int(relu) and has_bias == int(b is not None)
+        assert ksum == int(k.view(np.uint16).astype(np.uint64).sum())
+
+
+def test_unsupported_content_is_reported(host, tmp_path):
+    p = tmp_path / "not_hdf5.h5"
+    p.write_bytes(b"this is not an HDF5 file" * 10)
+    buf = C.create_string_buffer(512)
+    assert host.pth_h5_list(str(p).encode(), b"/", buf, 512) == -1 and b"no HDF5 signature" in buf.value
+    layers = nif_assets.synthetic_nif(hidden=64, layer_count=2)
+    good = str(tmp_path / "m.hdf5")
+    write_keras_h5(good, layers)
+    assert host.pth_h5_attr(good.encode(), b"/", b"missing_attr", buf, 512) == -1
+    dims, el = (C.c_size_t * 8)(), C.c_size_t()
+    assert host.pth_h5_dataset(good.encode(), b"/model_weights/nope", dims, C.byref(el), None, 0, buf, 512) == -1
+    assert b"no object 'nope'" in buf.value
+    trunc = tmp_path / "trunc.hdf5"
+    trunc.write_bytes(open(good, "rb").read()[:600])
+    assert host.pth_h5_list(str(trunc).encode(), b"/model_weights", buf, 512) == -1
+
+
+@pytest.mark.gpu
+def test_cli_renders_from_converted_hdf5(host, oracle, tmp_path):
+    """--assets <dir> with nif_metadata.txt + converted.hdf5 (the reference's own asset layout), end to end."""
+    exe = os.path.join(HOST, "ipu_trace")
+    W, H, spp = 64, 48, 4
+    assets = tmp_path / "assets.extra"
+    assets.mkdir()
+    layers = nif_assets.synthetic_nif()
+    nif_assets.write_metadata(str(assets / "nif_metadata.txt"))
+    write_keras_h5(str(assets / "converted.hdf5"), layers, vlen_config=True)
+    out = tmp_path / "img.png"
+    r = subprocess.run([exe, "--assets", str(assets), "-w", str(W), "-h", str(H), "-s", str(spp), "--samples-per-step",
+                        str(spp), "--max-path-length", "5", "-o", str(out)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    film = np.zeros((H, W, 3), dtype=np.float32)
+    ww, hh = C.c_size_t(), C.c_size_t()
+    host.pth_read_exr.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    assert host.pth_read_exr(str(tmp_path / "img.exr").encode(), film.ctypes.data, film.size, C.byref(ww), C.byref(hh)) == 0
+    cfg = oracle.make_config(width=W, height=H, max_path_length=5, env_mode=oracle.ENV_NIF)
+    ref = oracle.worklist(W, H)
+    oracle.render(cfg, oracle.Nif(layers, 12, nif_assets.URBAN_ALLEY_META["max"], nif_assets.folded_mean()), ref, 0, spp)
+    exp = np.stack([ref["b"], ref["g"], ref["r"]], -1).reshape(H, W, 3) / spp
+    np.testing.assert_allclose(film, exp, rtol=2e-2, atol=1e-6)
