@@ -297,11 +297,11 @@ int pack_nif(pt_handle h, const std::vector<HostLayer>& L, uint32_t E, std::vect
 template <int HID, int E, int NB, int WAVES>
 void launch_nif_v2(pt_handle h, const ptd::NifParams& N, int blocks) {
   using G = ptd::NifV2Geometry<HID, E, WAVES>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_set = 0;   // one bit per device: the attribute belongs to the function on a device
+  if (!(attr_set >> (h->cfg.device & 63) & 1ull)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ptd::nif_kernel_v2<HID, E, NB, WAVES>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
-    attr_set = true;
+    attr_set |= 1ull << (h->cfg.device & 63);
   }
   hipLaunchKernelGGL((ptd::nif_kernel_v2<HID, E, NB, WAVES>), dim3(blocks), dim3(64 * WAVES), G::LDS_BYTES, h->stream, N);
 }
@@ -309,11 +309,11 @@ void launch_nif_v2(pt_handle h, const ptd::NifParams& N, int blocks) {
 template <int HID, int E, int WAVES, int TPS, int DIAG = 0>
 void launch_nif_v3(pt_handle h, const ptd::NifParams& N, int blocks) {
   using G = ptd::NifV3Geometry<HID, E, WAVES, TPS>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_set = 0;   // one bit per device
+  if (!(attr_set >> (h->cfg.device & 63) & 1ull)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ptd::nif_kernel_v3<HID, E, WAVES, TPS, DIAG>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
-    attr_set = true;
+    attr_set |= 1ull << (h->cfg.device & 63);
   }
   hipLaunchKernelGGL((ptd::nif_kernel_v3<HID, E, WAVES, TPS, DIAG>), dim3(blocks), dim3(64 * WAVES), G::LDS_BYTES, h->stream, N);
 }
@@ -356,11 +356,11 @@ void launch_nif_t(pt_handle h, const ptd::NifParams& N, int blocks) {
 template <int HID, int E>
 void launch_nif_wide(pt_handle h, const ptd::NifParams& N, int blocks) {
   constexpr int lds = (HID / 16) * 2 * 1024 + (ptd::kMaxRegions + 1 + 256) * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_set = 0;   // one bit per device
+  if (!(attr_set >> (h->cfg.device & 63) & 1ull)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ptd::nif_wide_kernel<HID, E>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
+    attr_set |= 1ull << (h->cfg.device & 63);
   }
   hipLaunchKernelGGL((ptd::nif_wide_kernel<HID, E>), dim3(blocks), dim3(256), lds, h->stream, N);
 }
