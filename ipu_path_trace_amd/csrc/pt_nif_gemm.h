@@ -1,0 +1,348 @@
+// pt_nif_gemm.h -- wide NIFs (hidden 512 / 1024, BASELINE config C5) layer by layer.
+//
+// A 1024-wide activation vector fits neither a wave's registers nor, for more than 64 samples, a CU's LDS, and a
+// 64-sample tile re-streams 2 MiB of weights per layer for 134 MFLOP (64 FLOP per weight byte: the fused
+// nif_wide_kernel is bound by that stream at ~240 TFLOP/s).  At this width a layer is a large enough GEMM
+// (2 K N = 2.1 MFLOP against 4 KiB of activation traffic per sample) to run on its own: the queue is cut into
+// chunks of a few thousand 32-sample tiles whose activations ping-pong between two HBM buffers, and each layer
+// is one launch of nifg_layer_kernel over the chunk.
+//
+// Both operands are stored as ready-made MFMA fragments, 1 KiB pieces of [lane][8 fp16]:
+//   weights      piece (j, s)  = A operand of output tile j (32 features), k-step s    (pack_nif, ptmi.hip)
+//   activations  piece (t, s)  = B operand of sample tile t (32 samples), k-step s
+// and an accumulator tile, rounded to fp16 with bias and ReLU applied, IS the pair of pieces (t, 2j), (t, 2j + 1)
+// of the next layer (the k permutation is folded into the weight packing, as in pt_nif.h), so a layer's epilogue
+// writes whole pieces and the next layer's loader copies pieces global -> LDS by DMA with no transposition.
+// Rounding points are those of NifModel.cpp:295-326, identical to the fused kernels.
+#pragma once
+#include "pt_nif.h"
+
+namespace ptd {
+
+struct NifGemmParams {
+  const uint4* wpack;        // all weight pieces
+  const uint4* bpack;        // all bias tiles (64 B each)
+  uint32_t piece_base;       // first piece of this layer
+  uint32_t bias_base;        // first bias tile of this layer
+  uint32_t ks_act, ks_in;    // k-steps taken from activations / from the Fourier-feature pieces
+  uint32_t relu;
+  uint32_t n_ftiles;         // 32-feature output tiles of this layer (multiple of 8)
+  const uint4* act_in;       // [tile][act_stride] pieces
+  const uint4* feat;         // [tile][feat_stride] pieces
+  uint4* act_out;            // [tile][act_stride] pieces
+  uint32_t act_stride, feat_stride;
+  const uint32_t* total_tiles;   // device scalar: 32-sample tiles in the queue
+  uint32_t tile0, chunk_tiles;   // this launch covers queue tiles [tile0, tile0 + chunk_tiles)
+};
+
+constexpr int kGemmStages = 4;                  // ring slots
+constexpr int kGemmKps = 2;                     // k-steps per stage
+constexpr int kGemmStageBytes = kGemmKps * 16 * 1024;   // 8 A + 8 B pieces per k-step
+constexpr int kGemmBiasBytes = 4096;            // up to 64 output tiles
+constexpr int kGemmLdsBytes = kGemmBiasBytes + kGemmStages * kGemmStageBytes;
+
+// Tiles of the queue in this chunk (0 if the queue ends before it).
+__device__ __forceinline__ uint32_t chunk_tile_count(const uint32_t* total_tiles, uint32_t tile0, uint32_t chunk_tiles) {
+  const uint32_t total = *total_tiles;
+  if (total <= tile0) return 0u;
+  return (total - tile0 < chunk_tiles) ? total - tile0 : chunk_tiles;
+}
+
+// One dense layer over a chunk: D[256 features x 256 samples] per workgroup pass, 8 waves of 128 x 64
+// (4 x 2 accumulator tiles of 32 x 32).  Weights and activations arrive by LDS-DMA into a ring of four stages of
+// two k-steps (8 + 8 pieces each); every wave issues exactly four pieces per stage, so one counted s_waitcnt
+// covers the ring (see nif_kernel_v3), and the loader's cursor runs ahead across output blocks, so a block's
+// epilogue stores overlap the next block's first loads.
+//
+// Block order: workgroup g sits on XCD g % 8; the n_ftiles / 8 feature blocks of one sample block run at the
+// same time on the same XCD, so the sample block's activation pieces are fetched from HBM / Infinity Cache once
+// and hit that XCD's L2 for the other feature blocks; the layer's weights (<= 2 MiB) stay in every L2.
+__global__ __launch_bounds__(512, 2) void nifg_layer_kernel(const NifGemmParams P) {
+  constexpr int R = kGemmStages;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* bias_lds = smem;
+  char* ring = smem + kGemmBiasBytes;
+  const uint32_t ring_lds = __builtin_amdgcn_readfirstlane(
+      (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave & 1, wn = wave >> 1;
+  const int h = lane >> 5;
+
+  const uint32_t ntiles = chunk_tile_count(P.total_tiles, P.tile0, P.chunk_tiles);
+  const uint32_t nsb = (ntiles + 7u) / 8u;                 // sample blocks of 8 tiles
+  const uint32_t FB = P.n_ftiles / 8u;                     // feature blocks of 8 tiles
+  const uint32_t xcd = blockIdx.x & 7u, cidx = blockIdx.x >> 3, cpx = gridDim.x >> 3;
+  const uint32_t fb = cidx % FB, sbi0 = cidx / FB, spx = cpx / FB;
+  if (xcd + 8u * sbi0 >= nsb) return;                      // nothing for this workgroup (uniform)
+  const uint32_t nks = P.ks_act + P.ks_in;
+  const uint32_t nst = (nks + kGemmKps - 1u) / kGemmKps;
+
+  for (uint32_t i = threadIdx.x; i < P.n_ftiles * 4u; i += 512u)
+    reinterpret_cast<uint4*>(bias_lds)[i] = P.bpack[(size_t)P.bias_base * 4u + i];
+  __syncthreads();
+
+  // ---- loader: stage (pf_it, pf_st) -> ring slot pf_q % R; wave w loads weight tile w and sample tile w
+  uint32_t pf_it = 0, pf_st = 0, pf_q = 0;
+  auto issue_piece = [&](int i) {   // i = 0..3: (A, k0) (B, k0) (A, k1) (B, k1)
+    const uint32_t sb = xcd + 8u * (sbi0 + spx * pf_it);
+    uint32_t s = kGemmKps * pf_st + (uint32_t)(i >> 1);
+    if (s >= nks) s = nks - 1u;                            // odd k-step count: the last piece is loaded twice, unused
+    const char* src;
+    if ((i & 1) == 0) {
+      const uint32_t j = fb * 8u + (uint32_t)wave;
+      src = reinterpret_cast<const char*>(P.wpack) + ((size_t)(P.piece_base + j * nks + s) << 10);
+    } else {
+      const uint32_t t = sb * 8u + (uint32_t)wave;
+      src = (s < P.ks_act) ? reinterpret_cast<const char*>(P.act_in) + (((size_t)t * P.act_stride + s) << 10)
+                           : reinterpret_cast<const char*>(P.feat) + (((size_t)t * P.feat_stride + (s - P.ks_act)) << 10);
+    }
+    const uint32_t dst = ring_lds + (pf_q % R) * kGemmStageBytes + (uint32_t)(((i >> 1) * 16 + (i & 1) * 8 + wave) << 10);
+    glds16(src + lane * 16, dst);
+  };
+  auto stage_issued = [&]() {
+    pf_q += 1;
+    pf_st += 1;
+    if (pf_st == nst) {
+      // past the last block the cursor stays on it: those loads land in slots nobody reads (uniform load count)
+      if (xcd + 8u * (sbi0 + spx * (pf_it + 1u)) < nsb) { pf_it += 1; pf_st = 0; }
+      else pf_st = nst - 1u;
+    }
+  };
+#pragma unroll
+  for (int k = 0; k < R - 1; ++k) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_piece(i);
+    stage_issued();
+  }
+
+  uint32_t q = 0;            // consumer stage
+  uint32_t since_store = 3;  // stages since the last epilogue's 16 stores entered the vmcnt queue
+  for (uint32_t it = 0;; ++it) {
+    const uint32_t sb = xcd + 8u * (sbi0 + spx * it);
+    if (sb >= nsb) break;
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) { acc[a][0] = (f32x16)(0.0f); acc[a][1] = (f32x16)(0.0f); }
+
+    for (uint32_t st = 0; st < nst; ++st) {
+      // My pieces of this stage have landed when at most the younger operations are outstanding: two stages of
+      // four loads, plus the previous block's 16 stores while they are younger than the stage awaited.
+      if (nst < 4u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (since_store < 3u) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      asm volatile("s_barrier" ::: "memory");
+      since_store += 1;
+      const uint4* slot = reinterpret_cast<const uint4*>(ring + (q % R) * kGemmStageBytes) + lane;
+      q += 1;
+      const bool two = kGemmKps * st + 1u < nks;
+
+      half8 A0[4], B0[2], A1[4], B1[2];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) A0[a] = as_half8(slot[(4 * wm + a) * 64]);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) B0[b] = as_half8(slot[(8 + 2 * wn + b) * 64]);
+      issue_piece(0);
+      issue_piece(1);
+      // (with an odd k-step count the last stage's second half holds a copy of the first: read, not multiplied)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) A1[a] = as_half8(slot[(16 + 4 * wm + a) * 64]);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) B1[b] = as_half8(slot[(16 + 8 + 2 * wn + b) * 64]);
+      asm volatile("" : "+v"(A0[0]), "+v"(A0[1]), "+v"(A0[2]), "+v"(A0[3]), "+v"(B0[0]), "+v"(B0[1])::"memory");
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0[a], B0[0], acc[a][0], 0, 0, 0);
+        acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0[a], B0[1], acc[a][1], 0, 0, 0);
+      }
+      issue_piece(2);
+      issue_piece(3);
+      stage_issued();
+      if (two) {
+        asm volatile("" : "+v"(A1[0]), "+v"(A1[1]), "+v"(A1[2]), "+v"(A1[3]), "+v"(B1[0]), "+v"(B1[1])::"memory");
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1[a], B1[0], acc[a][0], 0, 0, 0);
+          acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1[a], B1[1], acc[a][1], 0, 0, 0);
+        }
+      }
+    }
+
+    // ---- epilogue: fp32 -> fp16 (RNE), + bias in fp16, ReLU; 16 whole pieces per wave, always stored (tiles past
+    // the end of the queue land in the buffer's padding), so the store count the waits above assume is exact
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const uint32_t j = fb * 8u + 4u * wm + a;
+      const uint4* bp = reinterpret_cast<const uint4*>(bias_lds) + ((size_t)j * 2 + h) * 2;
+      const half8 b_lo = as_half8(bp[0]), b_hi = as_half8(bp[1]);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        half8 l8, h8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { l8[i] = (_Float16)acc[a][b][i]; h8[i] = (_Float16)acc[a][b][8 + i]; }
+        l8 = l8 + b_lo;
+        h8 = h8 + b_hi;
+        if (P.relu) {
+          const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+          l8 = __builtin_elementwise_max(l8, z);
+          h8 = __builtin_elementwise_max(h8, z);
+        }
+        const uint32_t t = sb * 8u + 2u * wn + b;
+        uint4* out = P.act_out + ((size_t)t * P.act_stride + 2u * j) * 64 + lane;
+        union { half8 hh; uint4 u; } c0, c1;
+        c0.hh = l8;
+        c1.hh = h8;
+        out[0] = c0.u;
+        out[64] = c1.u;
+      }
+    }
+    since_store = 0;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the run-ahead loads before the wave ends
+}
+
+// tile_start[r] = first 32-sample tile of queue region r; tile_start[n_regions] = total.  One workgroup.
+__global__ __launch_bounds__(256) void nifg_scan_kernel(const uint32_t* region_count, uint32_t n_regions, uint32_t* tile_start) {
+  __shared__ uint32_t partial[256];
+  const uint32_t per = (n_regions + 255u) / 256u;
+  uint32_t sum = 0;
+  for (uint32_t i = 0; i < per; ++i) {
+    const uint32_t r = threadIdx.x * per + i;
+    if (r < n_regions) sum += (region_count[r] + 31u) / 32u;
+  }
+  partial[threadIdx.x] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t run = 0;
+    for (int i = 0; i < 256; ++i) { const uint32_t t = partial[i]; partial[i] = run; run += t; }
+    tile_start[n_regions] = run;
+  }
+  __syncthreads();
+  uint32_t run = partial[threadIdx.x];
+  for (uint32_t i = 0; i < per; ++i) {
+    const uint32_t r = threadIdx.x * per + i;
+    if (r < n_regions) { tile_start[r] = run; run += (region_count[r] + 31u) / 32u; }
+  }
+}
+
+// Region and offset of queue tile wt (binary search over the scan in LDS).
+struct TileRef {
+  uint32_t qbase, local, count;
+};
+__device__ __forceinline__ TileRef find_tile(const uint32_t* ts_lds, uint32_t n_regions, const NifParams& P, uint32_t wt) {
+  uint32_t lo = 0, hi = n_regions;
+  while (hi - lo > 1u) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (ts_lds[mid] <= wt) lo = mid; else hi = mid;
+  }
+  TileRef r;
+  r.local = (wt - ts_lds[lo]) * 32u;
+  r.count = P.region_count[lo];
+  r.qbase = lo * P.region_cap + r.local;
+  return r;
+}
+
+// Fourier features of a chunk as B pieces (NifModel.cpp:185-218): feat[tile][E / 4].  One wave per tile.
+template <int E>
+__global__ __launch_bounds__(256) void nifg_encode_kernel(const NifParams P, const uint32_t* tile_start, uint32_t tile0,
+                                                           uint32_t chunk_tiles, uint4* feat) {
+  constexpr int IS = E / 4;
+  __shared__ uint32_t ts[kMaxRegions + 1];
+  const uint32_t ntiles = chunk_tile_count(tile_start + P.n_regions, tile0, chunk_tiles);
+  if (blockIdx.x * 4u >= ntiles) return;
+  for (uint32_t i = threadIdx.x; i <= P.n_regions; i += 256u) ts[i] = tile_start[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 31, h = lane >> 5;
+  for (uint32_t lt = blockIdx.x * 4u + wave; lt < ntiles; lt += gridDim.x * 4u) {
+    const TileRef r = find_tile(ts, P.n_regions, P, tile0 + lt);
+    float coord = 0.5f;
+    if (r.local + c < r.count) coord = h ? P.q_v[r.qbase + c] : P.q_u[r.qbase + c];
+    const float x = (coord - 1.0f) * 2.0f;
+#pragma unroll
+    for (int s = 0; s < IS; ++s) {
+      union { half8 hh; uint4 u; } f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float a = (float)(_Float16)(x * (float)(1u << (4 * s + k)));
+        float sn, cs;
+        fast_sincos(a, sn, cs);
+        f.hh[k] = (_Float16)sn;
+        f.hh[4 + k] = (_Float16)cs;
+      }
+      feat[((size_t)lt * IS + s) * 64 + lane] = f.u;
+    }
+  }
+}
+
+// Head (3 outputs = rows 0..2 of one 32-row tile), decode (NifModel.cpp:221-245) and scatter
+// (codelets.cpp:366-382).  A wave takes four sample tiles so a weight piece is fetched once per 128 samples.
+__global__ __launch_bounds__(256) void nifg_head_kernel(const NifParams P, const NifGemmParams G, const uint32_t* tile_start) {
+  constexpr int NB = 4;
+  __shared__ uint32_t ts[kMaxRegions + 1];
+  const uint32_t ntiles = chunk_tile_count(tile_start + P.n_regions, G.tile0, G.chunk_tiles);
+  if (blockIdx.x * 4u * NB >= ntiles) return;
+  for (uint32_t i = threadIdx.x; i <= P.n_regions; i += 256u) ts[i] = tile_start[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 31, h = lane >> 5;
+  const uint4* wj = G.wpack + (size_t)G.piece_base * 64 + lane;
+  for (uint32_t lt0 = (blockIdx.x * 4u + wave) * NB; lt0 < ntiles; lt0 += gridDim.x * 4u * NB) {
+    f32x16 acc[NB];
+    const uint4* xb[NB];
+    const uint4* fbp[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      acc[b] = (f32x16)(0.0f);
+      const uint32_t lt = (lt0 + b < ntiles) ? lt0 + b : ntiles - 1u;   // clamp: recomputes a valid tile, not stored
+      xb[b] = G.act_in + (size_t)lt * G.act_stride * 64 + lane;
+      fbp[b] = G.feat + (size_t)lt * G.feat_stride * 64 + lane;
+    }
+#pragma unroll 4
+    for (uint32_t s = 0; s < G.ks_act; ++s) {
+      const half8 a = as_half8(wj[(size_t)s * 64]);
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, as_half8(xb[b][(size_t)s * 64]), acc[b], 0, 0, 0);
+    }
+    for (uint32_t s = 0; s < G.ks_in; ++s) {
+      const half8 a = as_half8(wj[(size_t)(G.ks_act + s) * 64]);
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, as_half8(fbp[b][(size_t)s * 64]), acc[b], 0, 0, 0);
+    }
+    const uint4* bp = G.bpack + ((size_t)G.bias_base * 2 + h) * 2;
+    const half8 b_lo = as_half8(bp[0]);
+    const float mean[3] = {P.mean0, P.mean1, P.mean2};
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      if (lt0 + b >= ntiles) continue;
+      const TileRef r = find_tile(ts, P.n_regions, P, G.tile0 + lt0 + b);
+      if (h == 0 && r.local + c < r.count) {
+        float bgr[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          _Float16 o16 = (_Float16)acc[b][k];
+          o16 = o16 + b_lo[k];
+          if (G.relu) o16 = o16 > (_Float16)0.0f ? o16 : (_Float16)0.0f;
+          float o = (float)o16 * P.max;
+          o = o + mean[k];
+          bgr[k] = P.log_tonemap ? __expf(o) : o;
+        }
+        const uint32_t qi = r.qbase + c;
+        if (P.out_bgr) {
+          P.out_bgr[3 * (size_t)qi + 0] = bgr[0];
+          P.out_bgr[3 * (size_t)qi + 1] = bgr[1];
+          P.out_bgr[3 * (size_t)qi + 2] = bgr[2];
+        } else {
+          const uint32_t path = P.q_path[qi];
+          P.rad_r[path] = bgr[2] * P.q_tr[qi];
+          P.rad_g[path] = bgr[1] * P.q_tg[qi];
+          P.rad_b[path] = bgr[0] * P.q_tb[qi];
+        }
+      }
+    }
+  }
+}
+
+}  // namespace ptd

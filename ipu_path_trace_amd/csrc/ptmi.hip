@@ -13,6 +13,7 @@
 
 #include "ptmi.h"
 #include "pt_nif.h"
+#include "pt_nif_gemm.h"
 #ifdef PTMI_DIAG_BUILD
 #include "pt_nif16.h"
 #endif
@@ -109,6 +110,11 @@ struct pt_context {
   uint4* d_wpack = nullptr;
   uint4* d_bpack = nullptr;
   uint64_t nif_flops = 0;
+  // layer-by-layer path of the wide networks (pt_nif_gemm.h): activation ping-pong and feature pieces of one chunk
+  uint4* d_gemm_act[2] = {nullptr, nullptr};
+  uint4* d_gemm_feat = nullptr;
+  uint32_t* d_tile_start = nullptr;
+  uint32_t gemm_chunk = 0;   // 32-sample tiles per chunk (multiple of 8); 0 = path not set up
 
   // stats
   pt_stats stats{};
@@ -465,9 +471,75 @@ void launch_nif_wide(pt_handle h, const ptd::NifParams& N, int blocks) {
   hipLaunchKernelGGL((ptd::nif_wide_kernel<HID, E>), dim3(blocks), dim3(256), lds, h->stream, N);
 }
 
+// Wide networks, one launch per layer over chunks of the queue (pt_nif_gemm.h).  The number of queue tiles is only
+// known on the device, so chunks are launched up to the queue's capacity and those past its end return at once.
+int launch_nif_gemm(pt_handle h, const ptd::NifParams& N) {
+  const uint32_t H = (uint32_t)h->nif_hidden, KS = H / 16, IS = (uint32_t)h->nif_emb / 4, NT = H / 32, FB = NT / 8;
+  const uint32_t n_layers = N.n_layers, chunk = h->gemm_chunk;
+  if (!chunk) return fail(h, PT_ERR_NOT_READY, "wide-NIF buffers are not allocated");
+  static unsigned long long attr_set = 0;   // one bit per device
+  if (!(attr_set >> (h->cfg.device & 63) & 1ull)) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ptd::nifg_layer_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, ptd::kGemmLdsBytes);
+    attr_set |= 1ull << (h->cfg.device & 63);
+  }
+  hipLaunchKernelGGL(ptd::nifg_scan_kernel, dim3(1), dim3(256), 0, h->stream, N.region_count, N.n_regions, h->d_tile_start);
+  const uint64_t max_tiles = (uint64_t)N.n_regions * ((N.region_cap + 31u) / 32u);
+  uint32_t grid = ((uint32_t)h->n_cus / (8u * FB)) * 8u * FB;
+  if (grid == 0) grid = 8u * FB;
+  ptd::NifGemmParams G{};
+  G.wpack = N.wpack;
+  G.bpack = N.bpack;
+  G.feat = h->d_gemm_feat;
+  G.act_stride = KS;
+  G.feat_stride = IS;
+  G.total_tiles = h->d_tile_start + N.n_regions;
+  G.chunk_tiles = chunk;
+  for (uint64_t tile0 = 0; tile0 < max_tiles; tile0 += chunk) {
+    G.tile0 = (uint32_t)tile0;
+    const uint32_t enc_blocks = (chunk + 3u) / 4u;
+    if (h->nif_emb == 12)
+      hipLaunchKernelGGL((ptd::nifg_encode_kernel<12>), dim3(enc_blocks), dim3(256), 0, h->stream, N, h->d_tile_start, G.tile0, chunk, h->d_gemm_feat);
+    else
+      return fail(h, PT_ERR_UNSUPPORTED_MODEL, "wide NIFs are instantiated for embedding 12");
+    for (uint32_t l = 0; l + 1 < n_layers; ++l) {
+      const bool concat = (N.concat_mask >> l) & 1u;
+      G.piece_base = N.piece_base[l];
+      G.bias_base = N.bias_base[l];
+      G.ks_act = l ? KS : 0u;
+      G.ks_in = (l == 0 || concat) ? IS : 0u;
+      G.relu = (N.relu_mask >> l) & 1u;
+      G.n_ftiles = NT;
+      G.act_in = h->d_gemm_act[(l + 1u) & 1u];
+      G.act_out = h->d_gemm_act[l & 1u];
+      hipLaunchKernelGGL(ptd::nifg_layer_kernel, dim3(grid), dim3(512), ptd::kGemmLdsBytes, h->stream, G);
+    }
+    const uint32_t l = n_layers - 1;
+    G.piece_base = N.piece_base[l];
+    G.bias_base = N.bias_base[l];
+    G.ks_act = KS;
+    G.ks_in = ((N.concat_mask >> l) & 1u) ? IS : 0u;
+    G.relu = (N.relu_mask >> l) & 1u;
+    G.n_ftiles = 1;
+    G.act_in = h->d_gemm_act[(l + 1u) & 1u];
+    G.act_out = nullptr;
+    hipLaunchKernelGGL(ptd::nifg_head_kernel, dim3((chunk + 15u) / 16u), dim3(256), 0, h->stream, N, G, h->d_tile_start);
+  }
+  return PT_OK;
+}
+
 int launch_nif(pt_handle h, const ptd::NifParams& N, int blocks) {
-  if (h->nif_emb == 12 && h->nif_hidden == 1024) { launch_nif_wide<1024, 12>(h, N, blocks); return PT_OK; }
-  if (h->nif_emb == 12 && h->nif_hidden == 512) { launch_nif_wide<512, 12>(h, N, blocks); return PT_OK; }
+  if (h->nif_emb == 12 && (h->nif_hidden == 1024 || h->nif_hidden == 512)) {
+#ifdef PTMI_DIAG_BUILD
+    // A/B switch of the profiling build: the fused 64-sample kernel with activations in LDS
+    static const bool fused = getenv("PTMI_NIF_WIDE") && !strcmp(getenv("PTMI_NIF_WIDE"), "fused");
+    if (fused) {
+      if (h->nif_hidden == 1024) launch_nif_wide<1024, 12>(h, N, blocks); else launch_nif_wide<512, 12>(h, N, blocks);
+      return PT_OK;
+    }
+#endif
+    return launch_nif_gemm(h, N);
+  }
   if (h->nif_emb == 12) {
     switch (h->nif_hidden) {
       case 64: launch_nif_t<64, 12>(h, N, blocks); return PT_OK;
@@ -597,6 +669,7 @@ int pt_destroy(pt_handle h) {
   (void)hipFree(h->acc.pix); (void)hipFree(h->acc.r); (void)hipFree(h->acc.g); (void)hipFree(h->acc.b); (void)hipFree(h->acc.count); (void)hipFree(h->acc.length);
   (void)hipFree(h->d_counters);
   (void)hipFree(h->d_wpack); (void)hipFree(h->d_bpack);
+  (void)hipFree(h->d_gemm_act[0]); (void)hipFree(h->d_gemm_act[1]); (void)hipFree(h->d_gemm_feat); (void)hipFree(h->d_tile_start);
   (void)hipFree(h->d_scratch);
   for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
   if (h->trace_stream) { (void)hipStreamSynchronize(h->trace_stream); (void)hipStreamDestroy(h->trace_stream); }
@@ -654,6 +727,20 @@ int pt_upload_nif(pt_handle h, const pt_layer* layers, uint32_t n_layers, uint32
   N.max = max;
   N.mean0 = mean[0]; N.mean1 = mean[1]; N.mean2 = mean[2];
   N.log_tonemap = log_tonemap;
+  if (hidden >= 512) {   // wide network: chunk buffers of the layer-by-layer path
+    const uint32_t chunk = 4096;
+    const size_t act_bytes = (size_t)chunk * (hidden / 16) * 1024, feat_bytes = (size_t)chunk * (embedding_dim / 4) * 1024;
+    for (int i = 0; i < 2; ++i) {
+      if (h->d_gemm_act[i]) PT_HIP(hipFree(h->d_gemm_act[i]));
+      h->d_gemm_act[i] = nullptr;
+      PT_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_gemm_act[i]), act_bytes));
+    }
+    if (h->d_gemm_feat) PT_HIP(hipFree(h->d_gemm_feat));
+    h->d_gemm_feat = nullptr;
+    PT_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_gemm_feat), feat_bytes));
+    if (!h->d_tile_start) PT_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_tile_start), (ptd::kMaxRegions + 1) * 4));
+    h->gemm_chunk = chunk;
+  }
   h->nif = N;
   h->nif_hidden = (int)hidden;
   h->nif_emb = (int)embedding_dim;
