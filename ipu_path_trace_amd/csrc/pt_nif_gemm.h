@@ -116,8 +116,24 @@ __global__ __launch_bounds__(512, 2) void nifg_layer_kernel(const NifGemmParams 
     stage_issued();
   }
 
+  // Consumer.  A stage's fragments are read one half-stage ahead of their MFMAs, across the barrier: the barrier sits
+  // in the MIDDLE of stage q (between its two k-steps) and certifies that stage q + 1 has landed, so the first
+  // k-step's fragments of stage q + 1 are fetched under the second k-step's MFMAs of stage q, and the second
+  // k-step's fragments under the first k-step's MFMAs.  Neither the barrier skew nor the burst of 8 waves x 6 LDS
+  // reads behind it is then followed by an MFMA that waits for it.
   uint32_t q = 0;            // consumer stage
-  uint32_t since_store = 3;  // stages since the last epilogue's 16 stores entered the vmcnt queue
+  uint32_t since_store = 2;  // stages since the last epilogue's 16 stores entered the vmcnt queue
+  half8 A0[4], B0[2], A1[4], B1[2];
+  {
+    if (nst < 4u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    const uint4* slot = reinterpret_cast<const uint4*>(ring) + lane;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) A0[a] = as_half8(slot[(4 * wm + a) * 64]);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) B0[b] = as_half8(slot[(8 + 2 * wn + b) * 64]);
+  }
   for (uint32_t it = 0;; ++it) {
     const uint32_t sb = xcd + 8u * (sbi0 + spx * it);
     if (sb >= nsb) break;
@@ -126,24 +142,10 @@ __global__ __launch_bounds__(512, 2) void nifg_layer_kernel(const NifGemmParams 
     for (int a = 0; a < 4; ++a) { acc[a][0] = (f32x16)(0.0f); acc[a][1] = (f32x16)(0.0f); }
 
     for (uint32_t st = 0; st < nst; ++st) {
-      // My pieces of this stage have landed when at most the younger operations are outstanding: two stages of
-      // four loads, plus the previous block's 16 stores while they are younger than the stage awaited.
-      if (nst < 4u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else if (since_store < 3u) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      asm volatile("s_barrier" ::: "memory");
-      since_store += 1;
       const uint4* slot = reinterpret_cast<const uint4*>(ring + (q % R) * kGemmStageBytes) + lane;
+      const uint4* next = reinterpret_cast<const uint4*>(ring + ((q + 1u) % R) * kGemmStageBytes) + lane;
       q += 1;
       const bool two = kGemmKps * st + 1u < nks;
-
-      half8 A0[4], B0[2], A1[4], B1[2];
-#pragma unroll
-      for (int a = 0; a < 4; ++a) A0[a] = as_half8(slot[(4 * wm + a) * 64]);
-#pragma unroll
-      for (int b = 0; b < 2; ++b) B0[b] = as_half8(slot[(8 + 2 * wn + b) * 64]);
-      issue_piece(0);
-      issue_piece(1);
       // (with an odd k-step count the last stage's second half holds a copy of the first: read, not multiplied)
 #pragma unroll
       for (int a = 0; a < 4; ++a) A1[a] = as_half8(slot[(16 + 4 * wm + a) * 64]);
@@ -151,13 +153,32 @@ __global__ __launch_bounds__(512, 2) void nifg_layer_kernel(const NifGemmParams 
       for (int b = 0; b < 2; ++b) B1[b] = as_half8(slot[(16 + 8 + 2 * wn + b) * 64]);
       asm volatile("" : "+v"(A0[0]), "+v"(A0[1]), "+v"(A0[2]), "+v"(A0[3]), "+v"(B0[0]), "+v"(B0[1])::"memory");
 #pragma unroll
-      for (int a = 0; a < 4; ++a) {
+      for (int a = 0; a < 2; ++a) {
+        acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0[a], B0[0], acc[a][0], 0, 0, 0);
+        acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0[a], B0[1], acc[a][1], 0, 0, 0);
+      }
+      issue_piece(0);
+      issue_piece(1);
+#pragma unroll
+      for (int a = 2; a < 4; ++a) {
         acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0[a], B0[0], acc[a][0], 0, 0, 0);
         acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0[a], B0[1], acc[a][1], 0, 0, 0);
       }
       issue_piece(2);
       issue_piece(3);
       stage_issued();
+      // My pieces of stage q + 1 have landed when at most the younger operations are outstanding: two stages of
+      // four loads, plus the previous block's 16 stores while they are younger than the stage awaited.  All of
+      // this stage's fragments are in registers (lgkmcnt(0)), so behind the barrier its slot is free as well.
+      if (nst < 4u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (since_store < 2u) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      since_store += 1;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) A0[a] = as_half8(next[(4 * wm + a) * 64]);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) B0[b] = as_half8(next[(8 + 2 * wn + b) * 64]);
       if (two) {
         asm volatile("" : "+v"(A1[0]), "+v"(A1[1]), "+v"(A1[2]), "+v"(A1[3]), "+v"(B1[0]), "+v"(B1[1])::"memory");
 #pragma unroll

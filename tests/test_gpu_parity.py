@@ -145,6 +145,53 @@ def test_render_with_nif_matches_oracle(oracle, ptmi_lib):
     r.close()
 
 
+def test_wide_nif_spans_chunks(oracle, ptmi_lib):
+    """Layer-by-layer path (pt_nif_gemm.h): a queue longer than one chunk of 4096 tiles, with a ragged last sample
+    block, must give the same numbers as the oracle for every sample."""
+    O = oracle
+    L = nif_assets.synthetic_nif(hidden=512, layer_count=3, seed=77)
+    meta = nif_assets.URBAN_ALLEY_META
+    mean = nif_assets.folded_mean()
+    onif = O.Nif(L, 12, meta["max"], mean)
+    r = ptmi_lib.Renderer(64, 64)
+    r.init_nif_weights(L, 12, meta["max"], mean)
+    rng = np.random.default_rng(11)
+    n = 4096 * 32 + 12345
+    u = rng.random(n, dtype=np.float32)
+    v = rng.random(n, dtype=np.float32)
+    got = r.nif_infer(u, v)
+    ref = onif.infer(u, v)
+    rel = np.abs(got - ref) / np.abs(ref)
+    assert rel.max() < NIF_RTOL_MAX, rel.max()
+    assert np.median(rel) < NIF_RTOL_MEDIAN
+    r.close()
+
+
+def test_render_with_wide_nif_matches_oracle(oracle, ptmi_lib):
+    """Whole step through the layer-by-layer NIF path: many queue regions with ragged counts."""
+    O = oracle
+    W = H = 96
+    L = nif_assets.synthetic_nif(hidden=512, layer_count=3, seed=78)
+    meta = nif_assets.URBAN_ALLEY_META
+    mean = nif_assets.folded_mean()
+    onif = O.Nif(L, 12, meta["max"], mean)
+    cfg = O.make_config(width=W, height=H, max_path_length=8, env_mode=O.ENV_NIF, env_rotation_degrees=-35.0)
+    ref = O.worklist(W, H)
+    st = O.render(cfg, onif, ref, 0, 5)
+    r = ptmi_lib.Renderer(W, H, max_path_length=8, iterations_per_batch=2)
+    r.init_nif_weights(L, 12, meta["max"], mean)
+    r.init_render_settings(env_rotation_degrees=-35.0, samples_per_step=5)
+    got = ptmi_lib.worklist(W, H)
+    r.setup(got)
+    r.path_trace()
+    gst = r.read_results(got)
+    assert np.array_equal(got["pathLength"], ref["pathLength"])
+    assert (gst.paths, gst.segments, gst.escaped) == (st.paths, st.segments, st.escaped)
+    for c in "rgb":
+        np.testing.assert_allclose(got[c], ref[c], rtol=NIF_RTOL_MAX, atol=1e-6)
+    r.close()
+
+
 def test_errors_are_reported(ptmi_lib):
     r = ptmi_lib.Renderer(32, 32)
     with pytest.raises(ptmi_lib.PtError):
