@@ -71,6 +71,11 @@ def main():
     ap.add_argument("--hidden", type=int, default=320)
     ap.add_argument("--layers", type=int, default=6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    # the reference's options of the same names (PathTracerApp.cpp:794-830); defaults keep the headline run unchanged
+    ap.add_argument("--save-interval", type=int, default=0,
+                    help="gather the HDR tiles to rank 0 every N steps (0: once, after the last timed step)")
+    ap.add_argument("--enable-load-balancing", action="store_true",
+                    help="re-deal image tiles between ranks by measured path length at every save interval")
     args = ap.parse_args()
 
     import torch
@@ -104,10 +109,12 @@ def main():
     layers = nif_assets.synthetic_nif(hidden=args.hidden, layer_count=args.layers,
                                       embedding_dim=meta["embedding_dimension"])
 
-    work = partition.tile_order_worklist(W, H, rank, world)
-    counts = partition.items_per_rank(W, H, world)
+    owner = partition.round_robin_owner(W, H, world)
+    work = partition.worklist_for_owner(W, H, owner, rank)
+    redeal = args.enable_load_balancing and world > 1 and args.save_interval > 0
+    counts = [partition.max_items_per_rank(W, H, world)] if redeal else partition.items_per_rank(W, H, world)
     stream = torch.cuda.current_stream().cuda_stream
-    r = ptmi.Renderer(W, H, max_work_items=work.size, max_path_length=depth, device=device_index, stream=stream)
+    r = ptmi.Renderer(W, H, max_work_items=max(counts), max_path_length=depth, device=device_index, stream=stream)
     r.init_nif_weights(layers, meta["embedding_dimension"], meta["max"], mean)   # program init_nif_weights
     r.init_render_settings(seed=1, aa_noise_scale=0.3, fov_degrees=90.0, samples_per_step=spp)
     r.setup(work)                                                                 # inputs resident in HBM
@@ -134,13 +141,40 @@ def main():
         else:
             dist.gather(hdr, gathered, dst=0)
 
+    film_sum = np.zeros((H, W, 3), dtype=np.float64) if rank == 0 else None   # sum over intervals of mean x steps
+    state = {"owner": owner, "work": work, "steps_in_interval": 0}
+
+    def hand_off(last):
+        """Save-interval film hand-off (AccumulatedImage::accumulate, AccumulatedImage.cpp:59-74): mean BGR per work
+        item -> one gather of HDR tiles to rank 0; optionally re-deal tiles by path length (N3) and start afresh."""
+        r.export_hdr_device(hdr.data_ptr(), state["work"].size)
+        gather_hdr()
+        if rank == 0 and world > 1 and (args.save_interval > 0):
+            film = partition.assemble_hdr(W, H, world, [g.cpu().numpy() for g in gathered], owner=state["owner"])
+            film_sum[...] += film.astype(np.float64) * state["steps_in_interval"]
+        if last or args.save_interval <= 0:
+            return
+        if redeal:
+            r.read_results(state["work"])                                     # per-item pathLength of the interval
+            cost = torch.from_numpy(partition.tile_costs(state["work"], W, H))
+            if not rehearsal:
+                cost = cost.cuda()
+            dist.all_reduce(cost, op=dist.ReduceOp.SUM)
+            state["owner"] = partition.deal_by_path_length(cost.cpu().numpy(), world)
+        state["work"] = partition.worklist_for_owner(W, H, state["owner"], rank)
+        r.setup(state["work"])                                                # zeroed accumulators for the next interval
+        state["steps_in_interval"] = 0
+
     for _ in range(args.warmup):
         r.path_trace()
+    if args.warmup and args.save_interval > 0:
+        r.setup(work)                                                         # intervals count timed steps only
     agg = {"escaped": 0, "segments": 0, "paths": 0, "nif_ms": 0.0, "trace_ms": 0.0, "acc_ms": 0.0, "nif_launches": 0}
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for step in range(args.steps):
         r.path_trace()
+        state["steps_in_interval"] += 1
         st = r.stats()
         agg["escaped"] += st.escaped
         agg["segments"] += st.segments
@@ -149,9 +183,9 @@ def main():
         agg["trace_ms"] += st.path_trace_ms
         agg["acc_ms"] += st.accumulate_ms
         agg["nif_launches"] += st.nif_launches
-    # save-interval film hand-off: mean BGR per work item -> RCCL gather of HDR tiles to rank 0
-    r.export_hdr_device(hdr.data_ptr(), work.size)
-    gather_hdr()
+        if args.save_interval > 0 and (step + 1) % args.save_interval == 0 and step + 1 < args.steps:
+            hand_off(last=False)
+    hand_off(last=True)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -200,7 +234,12 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(W, H, depth, layers, meta, mean)
         if world > 1:
-            film = partition.assemble_hdr(W, H, world, [g.cpu().numpy() for g in gathered])
+            if args.save_interval > 0:
+                film = (film_sum / args.steps).astype(np.float32)
+                out["config"]["save_interval"] = args.save_interval
+                out["config"]["load_balancing"] = bool(redeal)
+            else:
+                film = partition.assemble_hdr(W, H, world, [g.cpu().numpy() for g in gathered])
             out["config"]["film_mean"] = float(film.mean())
             out["config"]["film_nonzero_fraction"] = float((film.sum(axis=2) > 0).mean())
         if rehearsal:

@@ -38,6 +38,48 @@ def test_assemble_roundtrip():
     assert np.array_equal(partition.assemble_hdr(w, h, world, parts), truth)
 
 
+def test_deal_by_path_length_balances_and_keeps_tile_counts():
+    """N3 (LoadBalancer.cpp:141-192 across ranks): equal tile counts, near-equal cost, identical on every rank."""
+    rng = np.random.default_rng(3)
+    world = 8
+    cost = rng.integers(256, 256 * 8, size=4347).astype(np.float64)
+    cost[::world] *= 3.0            # adversarial for round-robin: every 8th tile is heavy -> rank 0 gets them all
+    rr = np.arange(cost.size) % world
+    owner = partition.deal_by_path_length(cost, world)
+    counts = np.bincount(owner, minlength=world)
+    assert counts.max() - counts.min() <= 1
+    load = np.bincount(owner, weights=cost, minlength=world)
+    load_rr = np.bincount(rr, weights=cost, minlength=world)
+    assert load.max() / load.mean() < 1.01
+    assert load_rr.max() / load_rr.mean() > 1.5
+    assert np.array_equal(owner, partition.deal_by_path_length(cost.copy(), world))
+    # two tiles per rank: exactly the reference's shortest+longest pairing
+    c = np.array([5.0, 1.0, 9.0, 3.0])
+    o = partition.deal_by_path_length(c, 2)
+    assert o[2] == o[1] and o[0] == o[3] and o[2] != o[0]
+
+
+def test_redealt_worklists_cover_every_pixel_once_and_reassemble():
+    w, h, world = 200, 120, 3
+    cost = np.random.default_rng(5).random(partition.tile_grid(w, h)[0] * partition.tile_grid(w, h)[1])
+    owner = partition.deal_by_path_length(cost, world)
+    seen = np.zeros((h, w), dtype=np.int32)
+    truth = np.random.default_rng(6).random((h, w, 3)).astype(np.float32)
+    parts = []
+    for r in range(world):
+        rec = partition.worklist_for_owner(w, h, owner, r)
+        assert rec.size <= partition.max_items_per_rank(w, h, world)
+        np.add.at(seen, (rec["v"], rec["u"]), 1)
+        parts.append(truth[rec["v"], rec["u"], :])
+    assert np.all(seen == 1)
+    assert np.array_equal(partition.assemble_hdr(w, h, world, parts, owner=owner), truth)
+    # tile_costs is the inverse bookkeeping: per-tile sums of what a step returned
+    rec = partition.worklist_for_owner(w, h, owner, 1)
+    rec["pathLength"] = 2
+    tc = partition.tile_costs(rec, w, h)
+    assert tc.sum() == 2 * rec.size and np.all(tc[owner != 1] == 0)
+
+
 _WORKER = r"""
 import os, sys
 import numpy as np, torch, torch.distributed as dist
@@ -63,6 +105,25 @@ if rank == 0:
     exp = np.stack([xx * 1.0, yy * 2.0, xx * 0.5 + yy], -1).astype(np.float32)
     assert np.array_equal(film, exp)
     print("GATHER_OK")
+# re-deal between save intervals: per-tile path-length sums are all-reduced, every rank derives the same deal
+rec["pathLength"] = 1 + (rec["u"] // 16 + rec["v"] // 16) % 5
+cost = torch.from_numpy(partition.tile_costs(rec, W, H))
+dist.all_reduce(cost, op=dist.ReduceOp.SUM)
+owner = partition.deal_by_path_length(cost.numpy(), world)
+both = [torch.empty(owner.size, dtype=torch.int32) for _ in range(world)]
+dist.all_gather(both, torch.from_numpy(owner))
+assert all(torch.equal(b, both[0]) for b in both)
+rec2 = partition.worklist_for_owner(W, H, owner, rank)
+cap = partition.max_items_per_rank(W, H, world)
+vals2 = np.stack([rec2["u"] * 1.0, rec2["v"] * 2.0, rec2["u"] * 0.5 + rec2["v"]], -1).astype(np.float32)
+hdr2 = torch.zeros((cap, 3), dtype=torch.float32)
+hdr2[: rec2.size] = torch.from_numpy(vals2)
+gathered2 = [torch.empty_like(hdr2) for _ in range(world)] if rank == 0 else None
+dist.gather(hdr2, gathered2, dst=0)
+if rank == 0:
+    film2 = partition.assemble_hdr(W, H, world, [g.numpy() for g in gathered2], owner=owner)
+    assert np.array_equal(film2, exp)
+    print("REDEAL_OK")
 dist.destroy_process_group()
 """
 
@@ -78,4 +139,4 @@ def test_hdr_gather_two_ranks_gloo(tmp_path):
     env = dict(os.environ, OMP_NUM_THREADS="1")
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
-    assert "GATHER_OK" in p.stdout
+    assert "GATHER_OK" in p.stdout and "REDEAL_OK" in p.stdout
