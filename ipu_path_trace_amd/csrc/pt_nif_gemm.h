@@ -50,13 +50,17 @@ __device__ __forceinline__ uint32_t chunk_tile_count(const uint32_t* total_tiles
 
 // One dense layer over a chunk: D[256 features x 256 samples] per workgroup pass, 8 waves of 128 x 64
 // (4 x 2 accumulator tiles of 32 x 32).  Weights and activations arrive by LDS-DMA into a ring of four stages of
-// two k-steps (8 + 8 pieces each); every wave issues exactly four pieces per stage, so one counted s_waitcnt
+// two k-steps (8 + 8 pieces each); every wave issues exactly four pieces per stage (two paired loads), so one counted s_waitcnt
 // covers the ring (see nif_kernel_v3), and the loader's cursor runs ahead across output blocks, so a block's
 // epilogue stores overlap the next block's first loads.
 //
 // Block order: workgroup g sits on XCD g % 8; the n_ftiles / 8 feature blocks of one sample block run at the
 // same time on the same XCD, so the sample block's activation pieces are fetched from HBM / Infinity Cache once
 // and hit that XCD's L2 for the other feature blocks; the layer's weights (<= 2 MiB) stay in every L2.
+// DIAG (timing-only builds, results invalid): bit 0 = no loads into the ring, bit 1 = no LDS reads of fragments,
+// bit 2 = no barrier, bit 3 = every load from one L2-hot piece, bit 4 = activation loads from one L2-hot piece.
+// (Tried and dropped: `nt` on the activation stream, -2.5 %; profiles/r01_g_c5_ablation.txt.)
+template <int DIAG>
 __global__ __launch_bounds__(512, 2) void nifg_layer_kernel(const NifGemmParams P) {
   constexpr int R = kGemmStages;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -82,23 +86,36 @@ __global__ __launch_bounds__(512, 2) void nifg_layer_kernel(const NifGemmParams 
     reinterpret_cast<uint4*>(bias_lds)[i] = P.bpack[(size_t)P.bias_base * 4u + i];
   __syncthreads();
 
-  // ---- loader: stage (pf_it, pf_st) -> ring slot pf_q % R; wave w loads weight tile w and sample tile w
+  // ---- loader: stage (pf_it, pf_st) -> ring slot pf_q % R.  Wave w loads weight tile w and sample tile w, both
+  // k-steps of each with one M0 set-up and one uniform base address (SGPR pair) + a constant per-lane offset: a
+  // tile's k-steps are contiguous in memory and in the slot ([A: tile][k][1 KiB] | [B: tile][k][1 KiB]), so the
+  // instruction's immediate offset addresses the second piece on both sides.  (With an odd k-step count the last
+  // stage's second piece is whatever follows in memory -- in bounds, never multiplied.)
+  const uint32_t lane16 = (uint32_t)lane * 16u;
   uint32_t pf_it = 0, pf_st = 0, pf_q = 0;
-  auto issue_piece = [&](int i) {   // i = 0..3: (A, k0) (B, k0) (A, k1) (B, k1)
-    const uint32_t sb = xcd + 8u * (sbi0 + spx * pf_it);
-    uint32_t s = kGemmKps * pf_st + (uint32_t)(i >> 1);
-    if (s >= nks) s = nks - 1u;                            // odd k-step count: the last piece is loaded twice, unused
-    const char* src;
-    if ((i & 1) == 0) {
+  auto issue_pair = [&](int which) {   // 0: weights, 1: activations
+    const uint32_t s0 = kGemmKps * pf_st;
+    const char* base;
+    if (which == 0) {
       const uint32_t j = fb * 8u + (uint32_t)wave;
-      src = reinterpret_cast<const char*>(P.wpack) + ((size_t)(P.piece_base + j * nks + s) << 10);
+      base = reinterpret_cast<const char*>(P.wpack) + ((size_t)(P.piece_base + j * nks + s0) << 10);
     } else {
-      const uint32_t t = sb * 8u + (uint32_t)wave;
-      src = (s < P.ks_act) ? reinterpret_cast<const char*>(P.act_in) + (((size_t)t * P.act_stride + s) << 10)
-                           : reinterpret_cast<const char*>(P.feat) + (((size_t)t * P.feat_stride + (s - P.ks_act)) << 10);
+      const uint32_t t = (xcd + 8u * (sbi0 + spx * pf_it)) * 8u + (uint32_t)wave;
+      base = (s0 < P.ks_act) ? reinterpret_cast<const char*>(P.act_in) + (((size_t)t * P.act_stride + s0) << 10)
+                             : reinterpret_cast<const char*>(P.feat) + (((size_t)t * P.feat_stride + (s0 - P.ks_act)) << 10);
     }
-    const uint32_t dst = ring_lds + (pf_q % R) * kGemmStageBytes + (uint32_t)(((i >> 1) * 16 + (i & 1) * 8 + wave) << 10);
-    glds16(src + lane * 16, dst);
+    if constexpr (DIAG & 8) base = reinterpret_cast<const char*>(P.wpack) + ((size_t)wave << 11);                    // every load L2-hot
+    if constexpr (DIAG & 16) { if (which) base = reinterpret_cast<const char*>(P.wpack) + ((size_t)wave << 11); }   // B loads L2-hot
+    const uint32_t dst = ring_lds + (pf_q % R) * kGemmStageBytes + (uint32_t)which * 16384u + ((uint32_t)wave << 11);
+    if constexpr (!(DIAG & 1)) {
+      uint32_t keep;
+      asm volatile(
+          "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+          "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\ts_mov_b32 m0, %0"
+          : "=&s"(keep)
+          : "v"(lane16), "s"(reinterpret_cast<uint64_t>(base)), "s"(dst)
+          : "memory");
+    }
   };
   auto stage_issued = [&]() {
     pf_q += 1;
@@ -111,8 +128,8 @@ __global__ __launch_bounds__(512, 2) void nifg_layer_kernel(const NifGemmParams 
   };
 #pragma unroll
   for (int k = 0; k < R - 1; ++k) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) issue_piece(i);
+    issue_pair(0);
+    issue_pair(1);
     stage_issued();
   }
 
@@ -130,9 +147,9 @@ __global__ __launch_bounds__(512, 2) void nifg_layer_kernel(const NifGemmParams 
     asm volatile("s_barrier" ::: "memory");
     const uint4* slot = reinterpret_cast<const uint4*>(ring) + lane;
 #pragma unroll
-    for (int a = 0; a < 4; ++a) A0[a] = as_half8(slot[(4 * wm + a) * 64]);
+    for (int a = 0; a < 4; ++a) A0[a] = as_half8(slot[(4 * wm + a) * 128]);
 #pragma unroll
-    for (int b = 0; b < 2; ++b) B0[b] = as_half8(slot[(8 + 2 * wn + b) * 64]);
+    for (int b = 0; b < 2; ++b) B0[b] = as_half8(slot[1024 + (2 * wn + b) * 128]);
   }
   for (uint32_t it = 0;; ++it) {
     const uint32_t sb = xcd + 8u * (sbi0 + spx * it);
@@ -147,25 +164,29 @@ __global__ __launch_bounds__(512, 2) void nifg_layer_kernel(const NifGemmParams 
       q += 1;
       const bool two = kGemmKps * st + 1u < nks;
       // (with an odd k-step count the last stage's second half holds a copy of the first: read, not multiplied)
+      if constexpr (!(DIAG & 2)) {
 #pragma unroll
-      for (int a = 0; a < 4; ++a) A1[a] = as_half8(slot[(16 + 4 * wm + a) * 64]);
+        for (int a = 0; a < 4; ++a) A1[a] = as_half8(slot[(4 * wm + a) * 128 + 64]);
 #pragma unroll
-      for (int b = 0; b < 2; ++b) B1[b] = as_half8(slot[(16 + 8 + 2 * wn + b) * 64]);
+        for (int b = 0; b < 2; ++b) B1[b] = as_half8(slot[1024 + (2 * wn + b) * 128 + 64]);
+      } else {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) A1[a] = A0[a];
+        B1[0] = B0[1]; B1[1] = B0[0];
+      }
       asm volatile("" : "+v"(A0[0]), "+v"(A0[1]), "+v"(A0[2]), "+v"(A0[3]), "+v"(B0[0]), "+v"(B0[1])::"memory");
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
         acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0[a], B0[0], acc[a][0], 0, 0, 0);
         acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0[a], B0[1], acc[a][1], 0, 0, 0);
       }
-      issue_piece(0);
-      issue_piece(1);
+      issue_pair(0);
 #pragma unroll
       for (int a = 2; a < 4; ++a) {
         acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0[a], B0[0], acc[a][0], 0, 0, 0);
         acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0[a], B0[1], acc[a][1], 0, 0, 0);
       }
-      issue_piece(2);
-      issue_piece(3);
+      issue_pair(1);
       stage_issued();
       // My pieces of stage q + 1 have landed when at most the younger operations are outstanding: two stages of
       // four loads, plus the previous block's 16 stores while they are younger than the stage awaited.  All of
@@ -173,12 +194,14 @@ __global__ __launch_bounds__(512, 2) void nifg_layer_kernel(const NifGemmParams 
       if (nst < 4u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else if (since_store < 2u) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if constexpr (!(DIAG & 4)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       since_store += 1;
+      if constexpr (!(DIAG & 2)) {
 #pragma unroll
-      for (int a = 0; a < 4; ++a) A0[a] = as_half8(next[(4 * wm + a) * 64]);
+        for (int a = 0; a < 4; ++a) A0[a] = as_half8(next[(4 * wm + a) * 128]);
 #pragma unroll
-      for (int b = 0; b < 2; ++b) B0[b] = as_half8(next[(8 + 2 * wn + b) * 64]);
+        for (int b = 0; b < 2; ++b) B0[b] = as_half8(next[1024 + (2 * wn + b) * 128]);
+      }
       if (two) {
         asm volatile("" : "+v"(A1[0]), "+v"(A1[1]), "+v"(A1[2]), "+v"(A1[3]), "+v"(B1[0]), "+v"(B1[1])::"memory");
 #pragma unroll
@@ -319,7 +342,6 @@ __global__ __launch_bounds__(256) void nifg_head_kernel(const NifParams P, const
       xb[b] = G.act_in + (size_t)lt * G.act_stride * 64 + lane;
       fbp[b] = G.feat + (size_t)lt * G.feat_stride * 64 + lane;
     }
-#pragma unroll 4
     for (uint32_t s = 0; s < G.ks_act; ++s) {
       const half8 a = as_half8(wj[(size_t)s * 64]);
 #pragma unroll

@@ -479,10 +479,22 @@ int launch_nif_gemm(pt_handle h, const ptd::NifParams& N) {
   if (!chunk) return fail(h, PT_ERR_NOT_READY, "wide-NIF buffers are not allocated");
   static unsigned long long attr_set = 0;   // one bit per device
   if (!(attr_set >> (h->cfg.device & 63) & 1ull)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ptd::nifg_layer_kernel),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ptd::nifg_layer_kernel<0>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, ptd::kGemmLdsBytes);
+#ifdef PTMI_DIAG_BUILD
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ptd::nifg_layer_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, ptd::kGemmLdsBytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ptd::nifg_layer_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, ptd::kGemmLdsBytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ptd::nifg_layer_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, ptd::kGemmLdsBytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ptd::nifg_layer_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, ptd::kGemmLdsBytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ptd::nifg_layer_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, ptd::kGemmLdsBytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ptd::nifg_layer_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, ptd::kGemmLdsBytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ptd::nifg_layer_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, ptd::kGemmLdsBytes);
+#endif
     attr_set |= 1ull << (h->cfg.device & 63);
   }
+#ifdef PTMI_DIAG_BUILD
+  static const int gdiag = getenv("PTMI_GEMM_DIAG") ? atoi(getenv("PTMI_GEMM_DIAG")) : 0;   // timing-only ablations
+#endif
   hipLaunchKernelGGL(ptd::nifg_scan_kernel, dim3(1), dim3(256), 0, h->stream, N.region_count, N.n_regions, h->d_tile_start);
   const uint64_t max_tiles = (uint64_t)N.n_regions * ((N.region_cap + 31u) / 32u);
   uint32_t grid = ((uint32_t)h->n_cus / (8u * FB)) * 8u * FB;
@@ -512,7 +524,16 @@ int launch_nif_gemm(pt_handle h, const ptd::NifParams& N) {
       G.n_ftiles = NT;
       G.act_in = h->d_gemm_act[(l + 1u) & 1u];
       G.act_out = h->d_gemm_act[l & 1u];
-      hipLaunchKernelGGL(ptd::nifg_layer_kernel, dim3(grid), dim3(512), ptd::kGemmLdsBytes, h->stream, G);
+#ifdef PTMI_DIAG_BUILD
+      if (gdiag == 1) { hipLaunchKernelGGL(ptd::nifg_layer_kernel<1>, dim3(grid), dim3(512), ptd::kGemmLdsBytes, h->stream, G); continue; }
+      if (gdiag == 2) { hipLaunchKernelGGL(ptd::nifg_layer_kernel<2>, dim3(grid), dim3(512), ptd::kGemmLdsBytes, h->stream, G); continue; }
+      if (gdiag == 3) { hipLaunchKernelGGL(ptd::nifg_layer_kernel<3>, dim3(grid), dim3(512), ptd::kGemmLdsBytes, h->stream, G); continue; }
+      if (gdiag == 4) { hipLaunchKernelGGL(ptd::nifg_layer_kernel<4>, dim3(grid), dim3(512), ptd::kGemmLdsBytes, h->stream, G); continue; }
+      if (gdiag == 7) { hipLaunchKernelGGL(ptd::nifg_layer_kernel<7>, dim3(grid), dim3(512), ptd::kGemmLdsBytes, h->stream, G); continue; }
+      if (gdiag == 8) { hipLaunchKernelGGL(ptd::nifg_layer_kernel<8>, dim3(grid), dim3(512), ptd::kGemmLdsBytes, h->stream, G); continue; }
+      if (gdiag == 16) { hipLaunchKernelGGL(ptd::nifg_layer_kernel<16>, dim3(grid), dim3(512), ptd::kGemmLdsBytes, h->stream, G); continue; }
+#endif
+      hipLaunchKernelGGL(ptd::nifg_layer_kernel<0>, dim3(grid), dim3(512), ptd::kGemmLdsBytes, h->stream, G);
     }
     const uint32_t l = n_layers - 1;
     G.piece_base = N.piece_base[l];
@@ -728,8 +749,12 @@ int pt_upload_nif(pt_handle h, const pt_layer* layers, uint32_t n_layers, uint32
   N.mean0 = mean[0]; N.mean1 = mean[1]; N.mean2 = mean[2];
   N.log_tonemap = log_tonemap;
   if (hidden >= 512) {   // wide network: chunk buffers of the layer-by-layer path
-    const uint32_t chunk = 4096;
-    const size_t act_bytes = (size_t)chunk * (hidden / 16) * 1024, feat_bytes = (size_t)chunk * (embedding_dim / 4) * 1024;
+    uint32_t chunk = 4096;
+#ifdef PTMI_DIAG_BUILD
+    if (const char* c = getenv("PTMI_GEMM_CHUNK")) chunk = (uint32_t)atoi(c) / 8u * 8u;   // chunk-size sweep of the profiling build
+    if (chunk == 0) chunk = 8;
+#endif
+    const size_t act_bytes = (size_t)chunk * (hidden / 16) * 1024, feat_bytes = (size_t)chunk * (embedding_dim / 4) * 1024 + 1024;   // + one piece: the paired loader reads one past an odd k-step count
     for (int i = 0; i < 2; ++i) {
       if (h->d_gemm_act[i]) PT_HIP(hipFree(h->d_gemm_act[i]));
       h->d_gemm_act[i] = nullptr;
