@@ -307,6 +307,18 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_byte_addr)
       : "memory");
 }
 
+// Two consecutive pieces (2 KiB of memory -> 2 KiB of LDS) with one M0 set-up: uniform base address in an SGPR pair,
+// constant per-lane offset, and the instruction's immediate offset, which applies to the global AND the LDS side.
+__device__ __forceinline__ void glds16x2(const void* sbase, uint32_t lane_off, uint32_t lds_byte_addr) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(lane_off), "s"(reinterpret_cast<uint64_t>(sbase)), "s"(lds_byte_addr)
+      : "memory");
+}
+
 template <int H, int E, int NB, int WAVES>
 __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void nif_kernel_v2(const NifParams P) {
   using G = NifV2Geometry<H, E, WAVES>;
@@ -589,12 +601,17 @@ struct NifV3Geometry {
   static constexpr int NT = H / 32;
   static constexpr int IS = E / 4;
   static constexpr int R = 3;
-  static constexpr int SLAB_PIECES = ((TPS * (KS + IS) + WAVES - 1) / WAVES) * WAVES;
-  static constexpr int PW = SLAB_PIECES / WAVES;
-  // pieces per wave of the smallest slabs (the head: KS pieces; layer 0: >= 2 tiles x IS pieces)
-  static constexpr int MINP = (KS >= 2 * WAVES && 2 * IS * 2 >= WAVES) ? 2 : ((KS >= WAVES) ? 1 : 0);
+  // pieces are loaded in pairs (one M0 set-up, one uniform base, immediate offset for the second piece)
+  static constexpr int SLAB_PIECES = ((TPS * (KS + IS) + 2 * WAVES - 1) / (2 * WAVES)) * (2 * WAVES);
+  static constexpr int PW = SLAB_PIECES / (2 * WAVES);                           // PAIRS each wave loads per slab
   static constexpr int SLOT_BYTES = SLAB_PIECES * 1024;
   static constexpr int T0 = (SLAB_PIECES / IS) < NT ? (SLAB_PIECES / IS) : NT;   // layer-0 tiles per slab
+  static constexpr int T0_LAST = (NT % T0) ? (NT % T0) : T0;
+  static constexpr int pairs_per_wave(int pieces) { return ((pieces + 1) / 2) / WAVES; }
+  static constexpr int min2(int a, int b) { return a < b ? a : b; }
+  // fewest load instructions any wave issues for any slab (head: KS pieces; hidden: TPS x KS; layer 0: T0 / T0_LAST x IS)
+  static constexpr int MINP = 2 * min2(min2(pairs_per_wave(KS), pairs_per_wave(TPS * KS)),
+                                       min2(pairs_per_wave(T0 * IS), pairs_per_wave(T0_LAST * IS)));
   static constexpr int SCAN_BYTES = ((kMaxRegions + 1) * 4 + 511) / 512 * 512;
   static constexpr int MAX_LAYERS = 8;                                           // bias tiles resident in LDS
   static constexpr int BIAS_BYTES = (((MAX_LAYERS - 1) * NT + 1) * 64 + 511) / 512 * 512;
@@ -669,12 +686,14 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void nif_kernel_v3(const Nif
     pf_first = P.piece_base[pf_l] + pf_j * ksteps;
     pf_slot = ring_lds + (pf_q % R) * G::SLOT_BYTES;
   };
-  auto slab_piece = [&](int i) {
+  const uint32_t lane16 = (uint32_t)lane * 16u;
+  auto slab_piece = [&](int i) {   // pair i of this wave: pieces 2 (wave + WAVES i), + 1
     if constexpr (DIAG & 1) return;
-    const uint32_t piece = (uint32_t)wave + (uint32_t)WAVES * i;
-    if (piece >= pf_cnt) return;                     // exact counts: a wave issues ceil((cnt - wave) / WAVES) pieces
-    const char* src = reinterpret_cast<const char*>(P.wpack) + ((size_t)(pf_first + piece) * 1024 + lane * 16);
-    glds16(src, pf_slot + piece * 1024u);
+    const uint32_t piece = 2u * ((uint32_t)wave + (uint32_t)WAVES * i);
+    if (piece >= pf_cnt) return;                     // exact counts: a wave issues ceil((pairs - wave) / WAVES) pairs
+    // (an odd slab's last pair also copies the piece that follows it in memory into an unused part of the slot)
+    const char* base = reinterpret_cast<const char*>(P.wpack) + ((size_t)(pf_first + piece) << 10);
+    glds16x2(base, lane16, pf_slot + piece * 1024u);
   };
   auto slab_end = [&]() {
     const uint32_t tiles_l = (pf_l + 1 == n_layers) ? 1u : (uint32_t)NT;

@@ -301,6 +301,7 @@ int pack_nif(pt_handle h, const std::vector<HostLayer>& L, uint32_t E, std::vect
     piece += ntiles * ksteps;
     btile += ntiles;
   }
+  wpack.resize(wpack.size() + 512, 0);   // the paired loaders may copy (never use) one piece past the last
   return PT_OK;
 }
 
