@@ -638,8 +638,12 @@ int pt_create(const pt_config* cfg, pt_handle* out) {
   hipDeviceProp_t prop;
   PT_HIPC(hipGetDeviceProperties(&prop, cfg->device));
   h->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  // The NIF stream outranks the trace stream: when NIF(b) and trace(b+1) become ready together, the NIF kernel's 256
+  // CU-sized workgroups must be placed first and the small trace workgroups fill what is left, not the reverse.
+  int prio_least = 0, prio_greatest = 0;
+  PT_HIPC(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
   if (cfg->stream) { h->stream = (hipStream_t)cfg->stream; }
-  else { PT_HIPC(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
+  else { PT_HIPC(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_greatest)); h->own_stream = true; }
 
   const uint32_t n = cfg->max_work_items;
   h->capacity = n;
@@ -677,7 +681,7 @@ int pt_create(const pt_config* cfg, pt_handle* out) {
     PT_HIPC(hipEventCreateWithFlags(&B.traced, hipEventDisableTiming));
     PT_HIPC(hipEventCreateWithFlags(&B.accumulated, hipEventDisableTiming));
   }
-  PT_HIPC(hipStreamCreateWithFlags(&h->trace_stream, hipStreamNonBlocking));
+  PT_HIPC(hipStreamCreateWithPriority(&h->trace_stream, hipStreamNonBlocking, prio_least));
 #undef PT_HIPC
   *out = h;
   return PT_OK;
