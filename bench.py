@@ -26,12 +26,21 @@ MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: ~
 
 def hbm_traffic_from_profile():
     """HBM bytes per NIF-kernel launch from the committed PMC passes (counters cannot be read inside this process)."""
-    path = os.path.join(ROOT, "profiles", "r01_d_pmc_hbm.json")
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):   # newest round first
+        try:
+            with open(path) as f:
+                doc = json.load(f)
+            for name, entry in doc.items():
+                if name.startswith("nif_kernel_v3") and "hbm_bytes_per_launch_corrected" in entry:
+                    return entry["hbm_bytes_per_launch_corrected"], os.path.relpath(path, ROOT)
+        except (OSError, ValueError, AttributeError):
+            continue
     try:
-        with open(path) as f:
-            return json.load(f)["nif_kernel_v3"]["hbm_bytes_per_launch_corrected"]
+        with open(os.path.join(ROOT, "profiles", "r01_d_pmc_hbm.json")) as f:
+            return json.load(f)["nif_kernel_v3"]["hbm_bytes_per_launch_corrected"], "profiles/r01_d_pmc_hbm.json"
     except (OSError, KeyError, ValueError):
-        return None
+        return None, None
 
 
 def cpu_baseline(width, height, depth, layers, meta, mean, target_seconds=12.0):
@@ -217,9 +226,9 @@ def main():
                          "achieved": achieved, "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_F16_DENSE_PEAK_TFLOPS,
                          "avg_launch_ms": agg["nif_ms"] / max(agg["nif_launches"], 1),
-                         "launches": agg["nif_launches"], "traffic": hbm_traffic_from_profile(),
+                         "launches": agg["nif_launches"], "traffic": hbm_traffic_from_profile()[0],
                          "traffic_unit": "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes: "
-                                         "profiles/r01_d_pmc_hbm.json)",
+                                         "%s)" % hbm_traffic_from_profile()[1],
                          "rank0_stage_ms": {"trace": agg["trace_ms"], "nif": agg["nif_ms"], "accumulate": agg["acc_ms"]}},
         }
         # Trace stages (ray-gen, intersect, shade, compact, accumulate): algorithmic HBM bytes 96 S + 88 E
