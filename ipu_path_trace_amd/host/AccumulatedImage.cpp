@@ -1,3 +1,4 @@
+#include "host_threads.hpp"
 #include "AccumulatedImage.hpp"
 
 #include <algorithm>
@@ -18,7 +19,7 @@ const Image3<std::uint8_t>& AccumulatedImage::updateLdrImage(std::size_t step, f
   const float scale = 1.f / step;
   const float exposureScale = std::pow(2.f, exposure);
   const float invGamma = 1.f / gamma;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(hostLoopThreads())
   for (std::size_t r = 0; r < hdrImage.rows; ++r) {
     const float* in = hdrImage.ptr(r);
     std::uint8_t* out = image.ptr(r);
@@ -43,7 +44,7 @@ void AccumulatedImage::saveImages(const std::string& fileName, std::size_t step,
 }
 
 void AccumulatedImage::accumulate(const std::vector<TraceRecord>& traces) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(hostLoopThreads())
   for (std::size_t i = 0; i < traces.size(); ++i) {
     const auto& t = traces[i];
     const std::size_t c = t.u, r = t.v;

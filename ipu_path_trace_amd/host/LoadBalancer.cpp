@@ -1,3 +1,4 @@
+#include "host_threads.hpp"
 #include "LoadBalancer.hpp"
 
 #include <algorithm>
@@ -16,7 +17,7 @@ constexpr unsigned kShuffleSeed = 142u;   // LoadBalancer.cpp:133
 std::size_t resetAndSumPathLengths(RecordList& list) {
   std::size_t total = 0;
   const std::size_t n = list.size();
-#pragma omp parallel for reduction(+ : total) schedule(static)
+#pragma omp parallel for reduction(+ : total) schedule(static) num_threads(hostLoopThreads())
   for (std::size_t i = 0; i < n; ++i) {
     total += list[i].pathLength;
     list[i].clearAccumulators();

@@ -217,8 +217,13 @@ void PathTracerApp::execute() {
     pt_log::debug_("NIF ms: {}", stats[0].nif_ms);
     pt_log::debug_("Total ms per step: {}", stats[0].total_ms);
 
+    const auto deviceDone = std::chrono::steady_clock::now();
     hostProcessing.waitForCompletion();    // join the previous async task before swapping (:703-708)
     traceState->work.getWork().swap();
+    pt_log::debug_("Device calls (setup + path_trace + read_results) wall ms: {}",
+                   std::chrono::duration<double, std::milli>(deviceDone - loopStartTime).count());
+    pt_log::debug_("Waited for host film task ms: {}",
+                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - deviceDone).count());
 
     hostProcessing.run([&, step, workPtr = &traceState->work, filmPtr = &traceState->film]() {
       filmPtr->accumulate(workPtr->getWork().inactive());

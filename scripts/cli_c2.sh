@@ -10,4 +10,4 @@ N.write_metadata("$A/nif_metadata.txt"); N.write_ptnif("$A/converted.ptnif", N.s
 PY
 make -C $ROOT/ipu_path_trace_amd/host -s
 $ROOT/ipu_path_trace_amd/host/ipu_trace --assets $A -w 1104 -h 1000 -s 1500 --samples-per-step 300 --ipus 1 --defer-attach \
-   -o /tmp/image.png --save-interval 10 --save-exe pt_graph --max-path-length 8
+   -o /tmp/image.png --save-interval 10 --save-exe pt_graph --max-path-length 8 ${CLI_EXTRA}
