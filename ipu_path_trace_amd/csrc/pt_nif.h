@@ -785,10 +785,22 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void nif_kernel_v3(const Nif
       const char* bias;   // this lane half's 32 bytes of packed bias
       uint32_t floor;     // packed fp16 pair: 0 (ReLU) or -inf (linear)
     };
-    auto epi_begin = [&](Pending& p, const f32x16& acc, uint32_t layer, int j) __attribute__((always_inline)) {
+    // Per-layer constants are fetched once per layer (layer_consts), not per tile: an s_load of a kernel argument
+    // indexed by the layer can only be awaited with lgkmcnt(0), which would also drain the LDS reads in flight.
+    struct LayerConsts {
+      const char* bias;   // this lane half's bias bytes of the layer's tile 0
+      uint32_t floor;
+    };
+    auto layer_consts = [&](uint32_t layer) -> LayerConsts {
+      LayerConsts c;
+      c.bias = bias_lds + ((size_t)P.bias_base[layer] * 2 + h) * 32;
+      c.floor = ((P.relu_mask >> layer) & 1u) ? 0u : 0xfc00fc00u;
+      return c;
+    };
+    auto epi_begin = [&](Pending& p, const f32x16& acc, const LayerConsts& c, int j) __attribute__((always_inline)) {
       p.acc = acc;
-      p.bias = bias_lds + ((size_t)(P.bias_base[layer] + j) * 2 + h) * 32;
-      p.floor = ((P.relu_mask >> layer) & 1u) ? 0u : 0xfc00fc00u;
+      p.bias = c.bias + j * 64;
+      p.floor = c.floor;
     };
     auto epi_chunk = [&](const Pending& p, auto chc, half8& o0, half8& o1, uint2 bias_now) __attribute__((always_inline)) {
       constexpr int ch = decltype(chc)::value;
@@ -828,18 +840,26 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void nif_kernel_v3(const Nif
     // One 32-feature output tile.  A fragments come from LDS in groups of GR, two groups in flight; the
     // empty asm pins that order (hipcc otherwise sinks every ds_read next to its MFMA and waits
     // lgkmcnt(0) per k-step) and makes the compiler wait for exactly the group about to multiply.
-    auto tile_mma = [&](const uint4* wj, half8 (&src)[KS], bool concat, f32x16& acc, auto&& after_group)
-                        __attribute__((always_inline)) {
+    // `A` outlives the tile: when the next tile sits in the same ring stage (already landed), its first group is
+    // fetched behind this tile's last group (`next`), so only the first tile after a barrier waits for LDS.
+    auto tile_mma = [&](const uint4* wj, half8 (&src)[KS], bool concat, f32x16& acc, half8 (&A)[2][GR], bool preloaded,
+                        const uint4* next, auto&& after_group) __attribute__((always_inline)) {
       acc = (f32x16)(0.0f);
-      half8 A[2][GR];
+      if (!preloaded) {
 #pragma unroll
-      for (int i = 0; i < GR; ++i) A[0][i] = (DIAG & 2) ? in[i % IS] : as_half8(wj[i * 64]);
+        for (int i = 0; i < GR; ++i) A[0][i] = (DIAG & 2) ? in[i % IS] : as_half8(wj[i * 64]);
+      }
       auto group = [&](auto gc) __attribute__((always_inline)) {
         constexpr int g2 = decltype(gc)::value;
         if constexpr (g2 + 1 < NG) {
 #pragma unroll
           for (int i = 0; i < GR; ++i)
             A[(g2 + 1) & 1][i] = (DIAG & 2) ? in[(g2 + i) % IS] : as_half8(wj[((g2 + 1) * GR + i) * 64]);
+        } else if constexpr (NG % 2 == 0 && !(DIAG & 2)) {
+          if (next) {
+#pragma unroll
+            for (int i = 0; i < GR; ++i) A[0][i] = as_half8(next[i * 64]);
+          }
         }
         if constexpr (GR == 4)
           asm volatile("" : "+v"(A[g2 & 1][0]), "+v"(A[g2 & 1][1]), "+v"(A[g2 & 1][2]), "+v"(A[g2 & 1][3])::"memory");
@@ -864,6 +884,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void nif_kernel_v3(const Nif
     {
       const uint4* slot = nullptr;
       Pending pend;
+      const LayerConsts lc = layer_consts(0);
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         if (j % T0 == 0) slot = stage_sync();
@@ -875,7 +896,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void nif_kernel_v3(const Nif
         for (int s = 0; s < IS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[s], in[s], acc, 0, 0, 0);
         if (j > 0) epi_all(pend, cur[2 * (j - 1)], cur[2 * (j - 1) + 1]);
         dma_slot();
-        epi_begin(pend, acc, 0, j);
+        epi_begin(pend, acc, lc, j);
       }
       epi_all(pend, cur[2 * (NT - 1)], cur[2 * (NT - 1) + 1]);
     }
@@ -887,11 +908,16 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void nif_kernel_v3(const Nif
       Pending pend;
       uint2 b_next = {0u, 0u};
       const uint4* slot = nullptr;
+      const LayerConsts lc = layer_consts(l);
+      half8 A[2][GR];
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         if (j % TPS == 0) slot = stage_sync();
         f32x16 acc;
-        tile_mma(slot + (size_t)(j % TPS) * ksteps * 64, src, concat, acc, [&](auto gc) __attribute__((always_inline)) {
+        const bool chained = NG % 2 == 0 && !(DIAG & 2);
+        const uint4* wj = slot + (size_t)(j % TPS) * ksteps * 64;
+        tile_mma(wj, src, concat, acc, A, chained && (j % TPS) != 0, (chained && (j % TPS) + 1 < TPS) ? wj + (size_t)ksteps * 64 : nullptr,
+                 [&](auto gc) __attribute__((always_inline)) {
           constexpr int g2 = decltype(gc)::value;
           if constexpr (g2 < 4) {
             if (j > 0) {
@@ -909,7 +935,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void nif_kernel_v3(const Nif
           if constexpr (NG < 3) epi_chunk(pend, IC<2>{}, dst[2 * (j - 1)], dst[2 * (j - 1) + 1], bias_at(pend, 2));
           if constexpr (NG < 4) epi_chunk(pend, IC<3>{}, dst[2 * (j - 1)], dst[2 * (j - 1) + 1], bias_at(pend, 3));
         }
-        epi_begin(pend, acc, l, j);
+        // The next tile's first fragments were requested before this tile's last MFMAs; retiring them here (a real
+        // s_waitcnt the compiler's counter model sees: lgkmcnt(0), vmcnt/expcnt untouched) keeps it from waiting
+        // for the following reads as well at the control-flow join behind the concat tail.
+        if (chained && (j % TPS) + 1 < TPS) __builtin_amdgcn_s_waitcnt(0xC07F);
+        epi_begin(pend, acc, lc, j);
         b_next = bias_at(pend, 0);   // read one tile ahead of chunk 0
       }
       epi_all(pend, dst[2 * (NT - 1)], dst[2 * (NT - 1) + 1]);
@@ -933,9 +963,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void nif_kernel_v3(const Nif
       const bool concat = (P.concat_mask >> l) & 1u;
       const uint4* slot = stage_sync();
       f32x16 acc;
-      tile_mma(slot, cur, concat, acc, [&](auto) __attribute__((always_inline)) { dma_slot(); });
+      half8 A[2][GR];
+      tile_mma(slot, cur, concat, acc, A, false, nullptr, [&](auto) __attribute__((always_inline)) { dma_slot(); });
       Pending pend;
-      epi_begin(pend, acc, l, 0);
+      epi_begin(pend, acc, layer_consts(l), 0);
       half8 o0, o1;
       epi_chunk(pend, IC<0>{}, o0, o1, bias_at(pend, 0));
       if (h == 0 && sample_valid) {
