@@ -868,6 +868,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void nif_kernel_v3(const Nif
 #pragma unroll
         for (int i = 0; i < GR; ++i)
           acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[g2 & 1][i], src[g2 * GR + i], acc, 0, 0, 0);
+        // keep the scheduler from sinking this group's MFMAs below the last group's fragment wait
+        if constexpr (g2 + 2 == NG) __builtin_amdgcn_sched_barrier(0);
         after_group(gc);
       };
       for_each_index(std::make_integer_sequence<int, NG>{}, group);
