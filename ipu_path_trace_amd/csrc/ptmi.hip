@@ -16,6 +16,7 @@
 #include "pt_nif_gemm.h"
 #ifdef PTMI_DIAG_BUILD
 #include "pt_nif16.h"
+#include "pt_nif_variants.h"
 #endif
 #include "pt_trace.h"
 
@@ -460,6 +461,7 @@ void launch_nif_t(pt_handle h, const ptd::NifParams& N, int blocks) {
   else launch_nif_v3<HID, E, 8, 2>(h, N, blocks);
 }
 
+#ifdef PTMI_DIAG_BUILD
 template <int HID, int E>
 void launch_nif_wide(pt_handle h, const ptd::NifParams& N, int blocks) {
   constexpr int lds = (HID / 16) * 2 * 1024 + (ptd::kMaxRegions + 1 + 256) * 4;
@@ -471,6 +473,7 @@ void launch_nif_wide(pt_handle h, const ptd::NifParams& N, int blocks) {
   }
   hipLaunchKernelGGL((ptd::nif_wide_kernel<HID, E>), dim3(blocks), dim3(256), lds, h->stream, N);
 }
+#endif
 
 // Wide networks, one launch per layer over chunks of the queue (pt_nif_gemm.h).  The number of queue tiles is only
 // known on the device, so chunks are launched up to the queue's capacity and those past its end return at once.
