@@ -182,6 +182,11 @@ def main():
 
     for _ in range(args.warmup):
         r.path_trace()
+    if world > 1 and args.warmup:
+        # untimed: the first gather sets up RCCL's point-to-point channels (lazily, on first use); the timed hand-off
+        # must measure the transfer, not the connection set-up
+        r.export_hdr_device(hdr.data_ptr(), work.size)
+        gather_hdr()
     if args.warmup and args.save_interval > 0:
         r.setup(work)                                                         # intervals count timed steps only
     agg = {"escaped": 0, "segments": 0, "paths": 0, "nif_ms": 0.0, "trace_ms": 0.0, "acc_ms": 0.0, "nif_launches": 0}
