@@ -140,11 +140,30 @@ __device__ __forceinline__ float disc_intersect(Vec3 o, Vec3 d, const SceneObjec
 
 enum StepResult { STEP_CONTINUE = 0, STEP_ESCAPED = 1, STEP_DEAD = 2 };
 
+// Per-object data a lane needs once it knows WHICH object it hit, in LDS so that the lane fetches its own object's
+// row by index.  (The scene also sits in the kernel arguments; holding all 6 x 13 constants in SGPRs across the
+// bounce loop for a select chain overflowed the SGPR file: 600 of the kernel's 2600 instructions were
+// v_writelane/v_readlane spill traffic.)
+struct HitRow {
+  float4 centre;   // cx, cy, cz, -
+  float4 normal;   // nx, ny, nz (disc), -
+  float4 colour;   // r, g, b, bits of (type | is_disc << 8)
+};
+__device__ __forceinline__ void fill_hit_table(const TraceParams& P, HitRow* tab) {
+#pragma unroll
+  for (int i = 0; i < kNumObjects; ++i) {
+    tab[i].centre = make_float4(P.obj[i].cx, P.obj[i].cy, P.obj[i].cz, 0.f);
+    tab[i].normal = make_float4(P.obj[i].nx, P.obj[i].ny, P.obj[i].nz, 0.f);
+    tab[i].colour = make_float4(P.obj[i].colr, P.obj[i].colg, P.obj[i].colb,
+                                __uint_as_float((uint32_t)P.obj[i].type | ((uint32_t)P.obj[i].is_disc << 8)));
+  }
+}
+
 // One iteration of the while loop of RayTraceKernel::compute (codelets.cpp:173-216) with the
 // AccumulateContributions fold (codelets.cpp:255-292) carried forward as throughput T.
 // Returns the path length (contribution-stack size, codelets.cpp:253) through `length` when the
 // path ends.
-__device__ __forceinline__ int bounce(const TraceParams& P, PathState& s, uint32_t& length) {
+__device__ __forceinline__ int bounce(const TraceParams& P, const HitRow* tab, PathState& s, uint32_t& length) {
   uint32_t w[4];
   philox4x32_10(s.pixel, s.sample, 1u + s.depth, 0x5054u, P.seed_lo, P.seed_hi, w);
   float rr = 1.0f;
@@ -157,11 +176,14 @@ __device__ __forceinline__ int bounce(const TraceParams& P, PathState& s, uint32
     rr = P.rr_factor;
   }
   // Scene::intersect (:183): nearest hit in declaration order.
+  // The loop stays rolled: one object's constants at a time are fetched from the kernel-argument segment (scalar
+  // loads, wave-uniform), instead of all of them living in SGPRs.
   int best = -1;
   float tbest = kInf;
-#pragma unroll
+#pragma unroll 1
   for (int i = 0; i < kNumObjects; ++i) {
-    float t = P.obj[i].is_disc ? disc_intersect(s.o, s.d, P.obj[i]) : sphere_intersect(s.o, s.d, P.obj[i]);
+    const SceneObject ob = P.obj[i];
+    float t = ob.is_disc ? disc_intersect(s.o, s.d, ob) : sphere_intersect(s.o, s.d, ob);
     if (t > kEps && t < tbest) { tbest = t; best = i; }
   }
   if (best < 0) {                                             // :184-190 ESCAPED
@@ -169,18 +191,11 @@ __device__ __forceinline__ int bounce(const TraceParams& P, PathState& s, uint32
     length = s.depth + 1u;
     return STEP_ESCAPED;
   }
-  // select the hit object's data (wave-uniform table, per-lane index)
-  float cx = 0, cy = 0, cz = 0, nx = 0, ny = 0, nz = 0, cr = 0, cg = 0, cb = 0;
-  int type = 0, is_disc = 0;
-#pragma unroll
-  for (int i = 0; i < kNumObjects; ++i) {
-    if (best == i) {
-      cx = P.obj[i].cx; cy = P.obj[i].cy; cz = P.obj[i].cz;
-      nx = P.obj[i].nx; ny = P.obj[i].ny; nz = P.obj[i].nz;
-      cr = P.obj[i].colr; cg = P.obj[i].colg; cb = P.obj[i].colb;
-      type = P.obj[i].type; is_disc = P.obj[i].is_disc;
-    }
-  }
+  // the hit object's row, by per-lane index
+  const float4 hc = tab[best].centre, hn = tab[best].normal, hcol = tab[best].colour;
+  const float cx = hc.x, cy = hc.y, cz = hc.z, nx = hn.x, ny = hn.y, nz = hn.z, cr = hcol.x, cg = hcol.y, cb = hcol.z;
+  const uint32_t bits = __float_as_uint(hcol.w);
+  const int type = (int)(bits & 0xffu), is_disc = (int)(bits >> 8);
   Vec3 hp = add(s.o, scale(s.d, tbest));
   s.o = hp;
   Vec3 n = is_disc ? mk(nx, ny, nz) : normalise(sub(hp, mk(cx, cy, cz)));
@@ -251,7 +266,8 @@ constexpr uint32_t kRefillThreshold = 20;  // refill once this many lanes are id
 
 __global__ __launch_bounds__(kTraceBlock) void trace_kernel(const TraceParams P) {
   __shared__ uint32_t wg_count;
-  if (threadIdx.x == 0) wg_count = 0;
+  __shared__ HitRow hit_table[kNumObjects];
+  if (threadIdx.x == 0) { wg_count = 0; fill_hit_table(P, hit_table); }
   __syncthreads();
 
   const uint32_t lane = threadIdx.x & 63u;
@@ -292,7 +308,7 @@ __global__ __launch_bounds__(kTraceBlock) void trace_kernel(const TraceParams P)
     }
     int res = STEP_CONTINUE;
     uint32_t length = 0;
-    if (active) res = bounce(P, st, length);
+    if (active) res = bounce(P, hit_table, st, length);
     const bool ended = active && res != STEP_CONTINUE;
     const bool escaped = active && res == STEP_ESCAPED;
     if (ended) {
@@ -335,6 +351,9 @@ struct PathRecordOut {  // layout of pt_path_record (include/ptmi.h)
 // One thread per requested path; same device functions as trace_kernel.
 __global__ void trace_paths_kernel(const TraceParams P, const uint16_t* u, const uint16_t* v, const uint32_t* sample,
                                    uint32_t n, PathRecordOut* out) {
+  __shared__ HitRow hit_table[kNumObjects];
+  if (threadIdx.x == 0) fill_hit_table(P, hit_table);
+  __syncthreads();
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   PathState st;
@@ -342,7 +361,7 @@ __global__ void trace_paths_kernel(const TraceParams P, const uint16_t* u, const
   start_path(P, (uint32_t)u[i] | ((uint32_t)v[i] << 16), sample[i], st, camx, camy);
   uint32_t length = 0;
   int res;
-  do { res = bounce(P, st, length); } while (res == STEP_CONTINUE);
+  do { res = bounce(P, hit_table, st, length); } while (res == STEP_CONTINUE);
   PathRecordOut r = {};
   r.length = length;
   r.escaped = (res == STEP_ESCAPED);

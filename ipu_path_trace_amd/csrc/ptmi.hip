@@ -93,6 +93,7 @@ struct pt_context {
     hipEvent_t accumulated = nullptr;  // accumulate kernel has consumed this set
   } bb[2];
   hipStream_t trace_stream = nullptr;
+  bool serial = false;   // profiling build only: trace kernels share the NIF stream
 
   // render settings
   bool settings_valid = false;
@@ -685,6 +686,10 @@ int pt_create(const pt_config* cfg, pt_handle* out) {
     PT_HIPC(hipEventCreateWithFlags(&B.accumulated, hipEventDisableTiming));
   }
   PT_HIPC(hipStreamCreateWithPriority(&h->trace_stream, hipStreamNonBlocking, prio_least));
+#ifdef PTMI_DIAG_BUILD
+  // profiling build: PTMI_SERIAL=1 runs the trace kernels on the NIF stream (no overlap) to measure interference
+  if (getenv("PTMI_SERIAL")) { (void)hipStreamDestroy(h->trace_stream); h->trace_stream = h->stream; h->serial = true; }
+#endif
 #undef PT_HIPC
   *out = h;
   return PT_OK;
@@ -701,7 +706,7 @@ int pt_destroy(pt_handle h) {
   (void)hipFree(h->d_gemm_act[0]); (void)hipFree(h->d_gemm_act[1]); (void)hipFree(h->d_gemm_feat); (void)hipFree(h->d_tile_start);
   (void)hipFree(h->d_scratch);
   for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
-  if (h->trace_stream) { (void)hipStreamSynchronize(h->trace_stream); (void)hipStreamDestroy(h->trace_stream); }
+  if (h->trace_stream && !h->serial) { (void)hipStreamSynchronize(h->trace_stream); (void)hipStreamDestroy(h->trace_stream); }
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return PT_OK;
