@@ -244,13 +244,13 @@ def main():
         }
         # Trace stages (ray-gen, intersect, shade, compact, accumulate): algorithmic HBM bytes 96 S + 88 E
         # over the trace kernels' own time.  The kernels run concurrently with the NIF kernel (second stream), so their
-        # durations are stretched: this is a lower bound; un-overlapped they take 17.5 ms per 331 M-path step
-        # with a constant sky (profiles/r01_j_configs.txt: 18.9 G path-samples/s) = 4.47 TB/s by the same accounting
+        # durations are stretched: this is a lower bound; un-overlapped they take 14.3 ms per 331 M-path step
+        # with a constant sky (profiles/r01_k_configs.txt: 23.2 G path-samples/s) = 5.5 TB/s by the same accounting
         # (`achieved_standalone`, a recorded figure, not measured in this run).
         trace_bytes = 96.0 * agg["segments"] + 88.0 * agg["escaped"]
         out["trace_stage"] = {"bound": "hbm", "unit": "GB/s", "peak": 8000.0,
                               "achieved_overlapped": trace_bytes / max(agg["trace_ms"] * 1e-3, 1e-9) / 1e9,
-                              "achieved_standalone": 4470.0, "bytes_per_path_sample": trace_bytes / max(agg["paths"], 1),
+                              "achieved_standalone": 5500.0, "bytes_per_path_sample": trace_bytes / max(agg["paths"], 1),
                               "rays_per_sec": agg["segments"] * world / elapsed}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(W, H, depth, layers, meta, mean)
