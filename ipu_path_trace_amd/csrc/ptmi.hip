@@ -93,6 +93,7 @@ struct pt_context {
     hipEvent_t accumulated = nullptr;  // accumulate kernel has consumed this set
   } bb[2];
   hipStream_t trace_stream = nullptr;
+  hipStream_t acc_stream = nullptr;   // accumulate(b) runs here, so NIF(b+1) follows NIF(b) back to back on `stream`
   bool serial = false;   // profiling build only: trace kernels share the NIF stream
 
   // render settings
@@ -686,6 +687,7 @@ int pt_create(const pt_config* cfg, pt_handle* out) {
     PT_HIPC(hipEventCreateWithFlags(&B.accumulated, hipEventDisableTiming));
   }
   PT_HIPC(hipStreamCreateWithPriority(&h->trace_stream, hipStreamNonBlocking, prio_least));
+  PT_HIPC(hipStreamCreateWithPriority(&h->acc_stream, hipStreamNonBlocking, prio_least));
 #ifdef PTMI_DIAG_BUILD
   // profiling build: PTMI_SERIAL=1 runs the trace kernels on the NIF stream (no overlap) to measure interference
   if (getenv("PTMI_SERIAL")) { (void)hipStreamDestroy(h->trace_stream); h->trace_stream = h->stream; h->serial = true; }
@@ -707,6 +709,7 @@ int pt_destroy(pt_handle h) {
   (void)hipFree(h->d_scratch);
   for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
   if (h->trace_stream && !h->serial) { (void)hipStreamSynchronize(h->trace_stream); (void)hipStreamDestroy(h->trace_stream); }
+  if (h->acc_stream) { (void)hipStreamSynchronize(h->acc_stream); (void)hipStreamDestroy(h->acc_stream); }
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return PT_OK;
@@ -837,8 +840,10 @@ int pt_path_trace(pt_handle h) {
   ptd::TraceParams P;
   fill_trace_params(h, P);
   P.n_items = n;
-  // Schedule: T(b) on trace_stream; N(b) and A(b) on stream.  T(b+1) overlaps N(b) (VALU under MFMA);
-  // buffer set b&1 is reused by T(b+2) once A(b) has consumed it.
+  // Schedule: T(b) on trace_stream, N(b) on stream, A(b) on acc_stream.  T(b+1) overlaps N(b) (VALU under MFMA),
+  // A(b) overlaps N(b+1) (a short HBM-bound pass), so the NIF launches follow each other without a gap;
+  // buffer set b&1 is reused by T(b+2) once A(b) has consumed it.  The A(b) are ordered among themselves (one
+  // stream), which keeps every pixel's fp32 sum in iteration order.
   size_t ev = 0;
   hipEvent_t e_begin = get_event(h, ev++);
   PT_HIP(hipEventRecord(e_begin, h->stream));
@@ -881,22 +886,29 @@ int pt_path_trace(pt_handle h) {
       h->stats.nif_launches += 1;
     }
     PT_HIP(hipEventRecord(n1, h->stream));
-    hipLaunchKernelGGL(ptd::accumulate_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, n, iters, B.plen, B.rad_r,
+    hipEvent_t a0 = get_event(h, ev + 5);
+    PT_HIP(hipStreamWaitEvent(h->acc_stream, n1, 0));
+    PT_HIP(hipEventRecord(a0, h->acc_stream));
+    hipLaunchKernelGGL(ptd::accumulate_kernel, dim3((n + 255) / 256), dim3(256), 0, h->acc_stream, n, iters, B.plen, B.rad_r,
                        B.rad_g, B.rad_b, h->acc, h->d_counters);
-    PT_HIP(hipEventRecord(a1, h->stream));
-    PT_HIP(hipEventRecord(B.accumulated, h->stream));
-    spans.push_back({ev + 3, ev + 4, 2});
-    ev += 5;
+    PT_HIP(hipEventRecord(a1, h->acc_stream));
+    PT_HIP(hipEventRecord(B.accumulated, h->acc_stream));
+    spans.push_back({ev + 5, ev + 4, 2});
+    ev += 6;
     h->stats.trace_launches += 1;
     h->stats.accumulate_launches += 1;
     done += iters;
     batch += 1;
   }
+  hipEvent_t e_acc = get_event(h, ev++);
+  PT_HIP(hipEventRecord(e_acc, h->acc_stream));
+  PT_HIP(hipStreamWaitEvent(h->stream, e_acc, 0));          // later work on `stream` sees the accumulated film
   hipEvent_t e_end = get_event(h, ev++);
   PT_HIP(hipEventRecord(e_end, h->stream));
   PT_HIP(hipGetLastError());
   PT_HIP(hipStreamSynchronize(h->stream));
   PT_HIP(hipStreamSynchronize(h->trace_stream));
+  PT_HIP(hipStreamSynchronize(h->acc_stream));
   h->sample_cursor += h->samples_per_step;
 
   unsigned long long counters[2] = {0, 0};
