@@ -4,6 +4,7 @@
 // -ffp-contract=off is part of the numerical contract (pt_device_math.h).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -391,11 +392,11 @@ int pack_nif16(pt_handle h, const std::vector<HostLayer>& L, uint32_t E, std::ve
 template <int HID, int E, int WAVES, int TPS>
 void launch_nif_v4(pt_handle h, const ptd::NifParams& N, int blocks) {
   using G = ptd::NifV4Geometry<HID, E, WAVES, TPS>;
-  static unsigned long long attr_set = 0;   // one bit per device
-  if (!(attr_set >> (h->cfg.device & 63) & 1ull)) {
+  static std::atomic<unsigned long long> attr_set{0};   // one bit per device; the host app drives devices from threads
+  if (!(attr_set.load(std::memory_order_relaxed) >> (h->cfg.device & 63) & 1ull)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ptd::nif_kernel_v4<HID, E, WAVES, TPS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
-    attr_set |= 1ull << (h->cfg.device & 63);
+    attr_set.fetch_or(1ull << (h->cfg.device & 63), std::memory_order_relaxed);
   }
   hipLaunchKernelGGL((ptd::nif_kernel_v4<HID, E, WAVES, TPS>), dim3(blocks), dim3(64 * WAVES), G::LDS_BYTES, h->stream, N);
 }
@@ -404,11 +405,11 @@ void launch_nif_v4(pt_handle h, const ptd::NifParams& N, int blocks) {
 template <int HID, int E, int NB, int WAVES>
 void launch_nif_v2(pt_handle h, const ptd::NifParams& N, int blocks) {
   using G = ptd::NifV2Geometry<HID, E, WAVES>;
-  static unsigned long long attr_set = 0;   // one bit per device: the attribute belongs to the function on a device
-  if (!(attr_set >> (h->cfg.device & 63) & 1ull)) {
+  static std::atomic<unsigned long long> attr_set{0};   // one bit per device; the host app drives devices from threads
+  if (!(attr_set.load(std::memory_order_relaxed) >> (h->cfg.device & 63) & 1ull)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ptd::nif_kernel_v2<HID, E, NB, WAVES>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
-    attr_set |= 1ull << (h->cfg.device & 63);
+    attr_set.fetch_or(1ull << (h->cfg.device & 63), std::memory_order_relaxed);
   }
   hipLaunchKernelGGL((ptd::nif_kernel_v2<HID, E, NB, WAVES>), dim3(blocks), dim3(64 * WAVES), G::LDS_BYTES, h->stream, N);
 }
@@ -416,11 +417,11 @@ void launch_nif_v2(pt_handle h, const ptd::NifParams& N, int blocks) {
 template <int HID, int E, int WAVES, int TPS, int DIAG = 0>
 void launch_nif_v3(pt_handle h, const ptd::NifParams& N, int blocks) {
   using G = ptd::NifV3Geometry<HID, E, WAVES, TPS>;
-  static unsigned long long attr_set = 0;   // one bit per device
-  if (!(attr_set >> (h->cfg.device & 63) & 1ull)) {
+  static std::atomic<unsigned long long> attr_set{0};   // one bit per device; the host app drives devices from threads
+  if (!(attr_set.load(std::memory_order_relaxed) >> (h->cfg.device & 63) & 1ull)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ptd::nif_kernel_v3<HID, E, WAVES, TPS, DIAG>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
-    attr_set |= 1ull << (h->cfg.device & 63);
+    attr_set.fetch_or(1ull << (h->cfg.device & 63), std::memory_order_relaxed);
   }
   hipLaunchKernelGGL((ptd::nif_kernel_v3<HID, E, WAVES, TPS, DIAG>), dim3(blocks), dim3(64 * WAVES), G::LDS_BYTES, h->stream, N);
 }
@@ -467,11 +468,11 @@ void launch_nif_t(pt_handle h, const ptd::NifParams& N, int blocks) {
 template <int HID, int E>
 void launch_nif_wide(pt_handle h, const ptd::NifParams& N, int blocks) {
   constexpr int lds = (HID / 16) * 2 * 1024 + (ptd::kMaxRegions + 1 + 256) * 4;
-  static unsigned long long attr_set = 0;   // one bit per device
-  if (!(attr_set >> (h->cfg.device & 63) & 1ull)) {
+  static std::atomic<unsigned long long> attr_set{0};   // one bit per device; the host app drives devices from threads
+  if (!(attr_set.load(std::memory_order_relaxed) >> (h->cfg.device & 63) & 1ull)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ptd::nif_wide_kernel<HID, E>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set |= 1ull << (h->cfg.device & 63);
+    attr_set.fetch_or(1ull << (h->cfg.device & 63), std::memory_order_relaxed);
   }
   hipLaunchKernelGGL((ptd::nif_wide_kernel<HID, E>), dim3(blocks), dim3(256), lds, h->stream, N);
 }
@@ -483,8 +484,8 @@ int launch_nif_gemm(pt_handle h, const ptd::NifParams& N) {
   const uint32_t H = (uint32_t)h->nif_hidden, KS = H / 16, IS = (uint32_t)h->nif_emb / 4, NT = H / 32, FB = NT / 8;
   const uint32_t n_layers = N.n_layers, chunk = h->gemm_chunk;
   if (!chunk) return fail(h, PT_ERR_NOT_READY, "wide-NIF buffers are not allocated");
-  static unsigned long long attr_set = 0;   // one bit per device
-  if (!(attr_set >> (h->cfg.device & 63) & 1ull)) {
+  static std::atomic<unsigned long long> attr_set{0};   // one bit per device; the host app drives devices from threads
+  if (!(attr_set.load(std::memory_order_relaxed) >> (h->cfg.device & 63) & 1ull)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ptd::nifg_layer_kernel<0>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, ptd::kGemmLdsBytes);
 #ifdef PTMI_DIAG_BUILD
@@ -496,7 +497,7 @@ int launch_nif_gemm(pt_handle h, const ptd::NifParams& N) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ptd::nifg_layer_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, ptd::kGemmLdsBytes);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ptd::nifg_layer_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, ptd::kGemmLdsBytes);
 #endif
-    attr_set |= 1ull << (h->cfg.device & 63);
+    attr_set.fetch_or(1ull << (h->cfg.device & 63), std::memory_order_relaxed);
   }
 #ifdef PTMI_DIAG_BUILD
   static const int gdiag = getenv("PTMI_GEMM_DIAG") ? atoi(getenv("PTMI_GEMM_DIAG")) : 0;   // timing-only ablations
