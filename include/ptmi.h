@@ -50,7 +50,7 @@ enum pt_status {
 
 enum { PT_AA_NORMAL = 0, PT_AA_UNIFORM = 1, PT_AA_TRUNCATED_NORMAL = 2 }; /* PathTracerApp.cpp:29-45 */
 enum { PT_SAMPLES_HALF = 0, PT_SAMPLES_FLOAT = 1 };                        /* PathTracerApp.cpp:297 */
-enum { PT_DTYPE_F16 = 0 };
+enum { PT_DTYPE_F16 = 0, PT_DTYPE_F32 = 1 };                                  /* Hdf5Model.cpp:109-133 */
 
 /* Compile-time parameters of the reference graph: the CLI options consumed by
  * PathTracerApp::build() and IpuPathTraceJob::buildGraph() (PathTracerApp.cpp:799-817,
@@ -72,12 +72,15 @@ typedef struct pt_config {
 
 /* One dense layer as NifModel streams it (src/neural_networks/DenseLayer.hpp:18-31,
  * NifModel.cpp:375-401): kernel row-major [rows = in][cols = out], bias [cols] or NULL,
- * raw fp16 bytes as stored in the Keras H5. */
+ * raw fp16 or fp32 bytes as stored in the Keras H5 (Hdf5Model.cpp:109-133 accepts both).
+ * Any Dense stack the reference's rule accepts is taken: first layer 4*embedding -> h0, every
+ * later layer's input width either the previous width or that + 4*embedding (concat(x, input),
+ * NifModel.cpp:305-308), head with 3 outputs; 2..16 layers, embedding 1..16, widths <= 2048. */
 typedef struct pt_layer {
   uint32_t rows, cols;
   const void* kernel;
   const void* bias;
-  int32_t dtype;                 /* PT_DTYPE_F16 */
+  int32_t dtype;                 /* PT_DTYPE_F16, or PT_DTYPE_F32 (rounded to binary16 on upload) */
   int32_t relu;                  /* activation == "relu" (NifModel.cpp:323-325) */
 } pt_layer;
 

@@ -32,6 +32,7 @@ struct NifParams {
   const uint4* wpack;              // 1 KiB pieces: [piece][lane] 16 B
   const uint4* bpack;              // [(ntile_index * 2 + h) * 2 + {0,1}] 16 B
   uint32_t n_layers;               // dense layers incl. the head
+  uint32_t n_freq;                 // true frequencies per coordinate; slots n_freq..E-1 (E padded to 4 | E) are zero features
   uint32_t piece_base[kMaxLayers]; // first piece of layer l
   uint32_t bias_base[kMaxLayers];  // first n-tile of layer l in bpack
   uint32_t concat_mask;            // bit l: layer l takes concat(x, input) (NifModel.cpp:305-308)
@@ -228,6 +229,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void nif_kernel_v2(const Nif
           const float a = (float)(_Float16)(x * (float)(1u << (4 * s + k)));
           float sn, cs;
           fast_sincos(a, sn, cs);
+          if (s == IS - 1 && k > 0 && (uint32_t)(4 * s + k) >= P.n_freq) { sn = 0.f; cs = 0.f; }   // padded frequency slot (E rounded up to 4 | E)
           f[k] = (_Float16)sn;
           f[4 + k] = (_Float16)cs;
         }
@@ -564,6 +566,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void nif_kernel_v3(const Nif
           float sn, cs;
           if constexpr (DIAG & 8) { sn = a; cs = a + 1.0f; }
           else fast_sincos(a, sn, cs);
+          if (s == IS - 1 && k > 0 && (uint32_t)(4 * s + k) >= P.n_freq) { sn = 0.f; cs = 0.f; }   // padded frequency slot (E rounded up to 4 | E)
           f[k] = (_Float16)sn;
           f[4 + k] = (_Float16)cs;
         }
@@ -878,7 +881,9 @@ __global__ void accumulate_kernel(uint32_t n, uint32_t iters, const uint8_t* ple
 __global__ void export_hdr_kernel(uint32_t n, Accum A, float* bgr) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  float scale = 1.f / (float)(uint16_t)A.count[i];
+  // an item that has no samples yet (after pt_setup / pt_clear_accumulators) exports 0, not 0/0
+  const uint32_t cnt = (uint16_t)A.count[i];
+  const float scale = cnt ? 1.f / (float)cnt : 0.f;
   bgr[3 * (size_t)i + 0] = A.b[i] * scale;
   bgr[3 * (size_t)i + 1] = A.g[i] * scale;
   bgr[3 * (size_t)i + 2] = A.r[i] * scale;

@@ -311,6 +311,7 @@ __global__ __launch_bounds__(256) void nifg_encode_kernel(const NifParams P, con
         const float a = (float)(_Float16)(x * (float)(1u << (4 * s + k)));
         float sn, cs;
         fast_sincos(a, sn, cs);
+        if (s == IS - 1 && k > 0 && (uint32_t)(4 * s + k) >= P.n_freq) { sn = 0.f; cs = 0.f; }   // padded frequency slot (E rounded up to 4 | E)
         f.hh[k] = (_Float16)sn;
         f.hh[4 + k] = (_Float16)cs;
       }

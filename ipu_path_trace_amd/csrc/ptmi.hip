@@ -4,6 +4,7 @@
 // -ffp-contract=off is part of the numerical contract (pt_device_math.h).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdio>
@@ -108,7 +109,8 @@ struct pt_context {
   bool env_const = false;
   float env_rgb[3] = {0, 0, 0};
   bool nif_valid = false;
-  int nif_hidden = 0, nif_emb = 0;
+  int nif_hidden = 0, nif_emb = 0;   // PADDED hidden width / embedding dimension the kernels are instantiated for
+  bool nif_gemm = false;  // layer-by-layer path (pt_nif_gemm.h)
   bool nif_m16 = false;   // weights packed for nif_kernel_v4 (16x16x32 MFMA) rather than the 32x32x16 kernels
   ptd::NifParams nif{};
   uint4* d_wpack = nullptr;
@@ -233,6 +235,71 @@ TraceGrid trace_grid(uint32_t total) {
   return g;
 }
 
+// ---- NIF shape normalisation ---------------------------------------------------------------
+// The reference builds whatever Dense stack the H5 describes (NifModel.cpp:295-326).  The MFMA kernels want a uniform
+// hidden width (a multiple of 32 for the register-resident kernels, of 256 for the layer-by-layer path) and 4 | E, so
+// the stack is zero-padded to that: a padded output feature has zero weights and zero bias (its activation is 0 with
+// or without ReLU), a padded input row multiplies it by zero, and a padded frequency slot (E not a multiple of 4) has
+// zero weights and a zero feature (NifParams::n_freq).  Arithmetic on the true entries is unchanged.
+struct NifPlan {
+  uint32_t E = 0, Ep = 0;   // frequencies per coordinate: true / padded to a multiple of 4
+  uint32_t Hp = 0;          // padded uniform hidden width
+  bool gemm = false;        // layer-by-layer path (pt_nif_gemm.h) instead of the register-resident kernels
+};
+
+constexpr uint32_t kMaxFusedHidden = 320;    // nif_kernel_v3/v2: two activation vectors of H halves per sample in VGPRs
+constexpr uint32_t kMaxGemmHidden = 2048;    // nifg_layer_kernel: bias tiles of one layer in 4 KiB of LDS
+
+int normalize_nif(pt_handle h, const std::vector<HostLayer>& L, uint32_t E, std::vector<HostLayer>& out, NifPlan& plan) {
+  const uint32_t n = (uint32_t)L.size();
+  if (n < 2 || n > ptd::kMaxLayers) return fail(h, PT_ERR_UNSUPPORTED_MODEL, "NIF must have 2..16 dense layers");
+  if (E == 0 || E > 16) return fail(h, PT_ERR_UNSUPPORTED_MODEL, "embedding dimension must be in 1..16");
+  const uint32_t in_dim = 4 * E, Ep = (E + 3u) / 4u * 4u, in_p = 4 * Ep;
+  if (L[0].rows != in_dim) return fail(h, PT_ERR_UNSUPPORTED_MODEL, "first layer must take the 4*embedding Fourier features");
+  if (L[n - 1].cols != 3) return fail(h, PT_ERR_UNSUPPORTED_MODEL, "NIF head must have 3 outputs (BGR)");
+  uint32_t widest = 0;
+  for (uint32_t l = 0; l + 1 < n; ++l) widest = std::max(widest, L[l].cols);
+  plan.E = E;
+  plan.Ep = Ep;
+  plan.gemm = widest > kMaxFusedHidden;
+  plan.Hp = plan.gemm ? (widest + 255u) / 256u * 256u : (widest + 31u) / 32u * 32u;
+  if (plan.Hp > kMaxGemmHidden) return fail(h, PT_ERR_UNSUPPORTED_MODEL, "hidden layers wider than 2048 are not supported");
+  const uint32_t Hp = plan.Hp;
+  out.assign(n, HostLayer());
+  uint32_t prev = 0;   // true width of the previous layer's output
+  for (uint32_t l = 0; l < n; ++l) {
+    const HostLayer& Y = L[l];
+    bool concat = false;
+    if (l == 0) {
+      // (rows == in_dim checked above)
+    } else if (Y.rows == prev) {
+    } else if (Y.rows == prev + in_dim) {   // NifModel.cpp:305-308: x = concat(x, input) when the widths differ
+      concat = true;
+    } else {
+      return fail(h, PT_ERR_UNSUPPORTED_MODEL, "layer " + std::to_string(l) + ": input width " + std::to_string(Y.rows) +
+                                                   " is neither the previous layer's width nor that plus the 4*embedding features");
+    }
+    HostLayer& Z = out[l];
+    const bool feats = (l == 0) || concat;
+    const uint32_t act_p = l ? Hp : 0u, act_t = l ? prev : 0u;
+    Z.rows = act_p + (feats ? in_p : 0u);
+    Z.cols = (l + 1 == n) ? 3u : Hp;
+    Z.relu = Y.relu;
+    Z.kernel.assign((size_t)Z.rows * Z.cols, 0);
+    for (uint32_t r = 0; r < act_t; ++r)
+      memcpy(&Z.kernel[(size_t)r * Z.cols], &Y.kernel[(size_t)r * Y.cols], (size_t)Y.cols * 2);
+    if (feats)
+      for (uint32_t f = 0; f < in_dim; ++f)   // feature order [sin u, sin v, cos u, cos v] x E (NifModel.cpp:216)
+        memcpy(&Z.kernel[(size_t)(act_p + (f / E) * Ep + (f % E)) * Z.cols], &Y.kernel[(size_t)(act_t + f) * Y.cols], (size_t)Y.cols * 2);
+    if (!Y.bias.empty()) {
+      Z.bias.assign(Z.cols, 0);
+      memcpy(Z.bias.data(), Y.bias.data(), (size_t)Y.cols * 2);
+    }
+    prev = Y.cols;
+  }
+  return PT_OK;
+}
+
 // ---- NIF weight packing -------------------------------------------------------------------
 // Piece (l, j, s): the A operand of one v_mfma_f32_32x32x16_f16: lane (r = lane & 31, hh = lane >> 5)
 // holds W^T[32 j + r][k(hh, 0..7)], where k() is the k-step's map onto rows of the Keras kernel:
@@ -309,6 +376,7 @@ int pack_nif(pt_handle h, const std::vector<HostLayer>& L, uint32_t E, std::vect
   return PT_OK;
 }
 
+#ifdef PTMI_DIAG_BUILD
 // The same network packed for nif_kernel_v4 (v_mfma_f32_16x16x32_f16, pt_nif16.h).  Piece (l, j, s, ft): lane
 // (r = lane & 15, qg = lane >> 4) holds W^T[32 j + 16 ft + r][k(qg, 0..7)] with
 //  * activation k-step s:  k = 32 s + (e < 4 ? 4 qg + e : 16 + 4 qg + (e - 4))      (accumulator-as-operand order)
@@ -388,6 +456,8 @@ int pack_nif16(pt_handle h, const std::vector<HostLayer>& L, uint32_t E, std::ve
   return PT_OK;
 }
 
+#endif
+
 #ifdef PTMI_DIAG_BUILD
 template <int HID, int E, int WAVES, int TPS>
 void launch_nif_v4(pt_handle h, const ptd::NifParams& N, int blocks) {
@@ -402,28 +472,33 @@ void launch_nif_v4(pt_handle h, const ptd::NifParams& N, int blocks) {
 }
 #endif
 
+// Dynamic-LDS opt-in of a kernel, once per device (one bit per device: the host app drives devices from threads).
+int set_dynamic_lds(pt_handle h, const void* fn, int bytes, std::atomic<unsigned long long>& done) {
+  const unsigned long long bit = 1ull << (h->cfg.device & 63);
+  if (done.load(std::memory_order_acquire) & bit) return PT_OK;
+  PT_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  done.fetch_or(bit, std::memory_order_release);
+  return PT_OK;
+}
+
 template <int HID, int E, int NB, int WAVES>
-void launch_nif_v2(pt_handle h, const ptd::NifParams& N, int blocks) {
+int launch_nif_v2(pt_handle h, const ptd::NifParams& N, int blocks) {
   using G = ptd::NifV2Geometry<HID, E, WAVES>;
-  static std::atomic<unsigned long long> attr_set{0};   // one bit per device; the host app drives devices from threads
-  if (!(attr_set.load(std::memory_order_relaxed) >> (h->cfg.device & 63) & 1ull)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ptd::nif_kernel_v2<HID, E, NB, WAVES>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
-    attr_set.fetch_or(1ull << (h->cfg.device & 63), std::memory_order_relaxed);
-  }
+  static std::atomic<unsigned long long> attr_set{0};
+  if (int rc = set_dynamic_lds(h, reinterpret_cast<const void*>(&ptd::nif_kernel_v2<HID, E, NB, WAVES>), G::LDS_BYTES, attr_set)) return rc;
   hipLaunchKernelGGL((ptd::nif_kernel_v2<HID, E, NB, WAVES>), dim3(blocks), dim3(64 * WAVES), G::LDS_BYTES, h->stream, N);
+  PT_HIP(hipGetLastError());
+  return PT_OK;
 }
 
 template <int HID, int E, int WAVES, int TPS, int DIAG = 0>
-void launch_nif_v3(pt_handle h, const ptd::NifParams& N, int blocks) {
+int launch_nif_v3(pt_handle h, const ptd::NifParams& N, int blocks) {
   using G = ptd::NifV3Geometry<HID, E, WAVES, TPS>;
-  static std::atomic<unsigned long long> attr_set{0};   // one bit per device; the host app drives devices from threads
-  if (!(attr_set.load(std::memory_order_relaxed) >> (h->cfg.device & 63) & 1ull)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ptd::nif_kernel_v3<HID, E, WAVES, TPS, DIAG>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
-    attr_set.fetch_or(1ull << (h->cfg.device & 63), std::memory_order_relaxed);
-  }
+  static std::atomic<unsigned long long> attr_set{0};
+  if (int rc = set_dynamic_lds(h, reinterpret_cast<const void*>(&ptd::nif_kernel_v3<HID, E, WAVES, TPS, DIAG>), G::LDS_BYTES, attr_set)) return rc;
   hipLaunchKernelGGL((ptd::nif_kernel_v3<HID, E, WAVES, TPS, DIAG>), dim3(blocks), dim3(64 * WAVES), G::LDS_BYTES, h->stream, N);
+  PT_HIP(hipGetLastError());
+  return PT_OK;
 }
 
 #ifdef PTMI_DIAG_BUILD
@@ -446,37 +521,61 @@ bool launch_nif_diag(pt_handle h, const ptd::NifParams& N, int blocks) {
 }
 #endif
 
+// Register-resident kernels, one instantiation per (padded hidden width, padded embedding): v3 keeps the bias tiles of
+// at most 8 layers resident in LDS; deeper networks take the v2 ring (layer 0 resident).  A ring stage of v3 carries
+// two output tiles where the tile count is even, else one.
 template <int HID, int E>
-void launch_nif_t(pt_handle h, const ptd::NifParams& N, int blocks) {
+int launch_nif_t(pt_handle h, const ptd::NifParams& N, int blocks) {
+  constexpr int TPS = ((HID / 32) % 2 == 0) ? 2 : 1;
 #ifdef PTMI_DIAG_BUILD
-  if (h->nif_m16) { launch_nif_v4<HID, E, 8, 2>(h, N, blocks); return; }
+  if constexpr (HID == 320 && E == 12) {
+    if (h->nif_m16) { launch_nif_v4<HID, E, 8, 2>(h, N, blocks); return PT_OK; }
+    if (launch_nif_diag<HID, E>(h, N, blocks)) return PT_OK;
+    // A/B switch of the profiling build: 1 = weights straight from L2, 2 = LDS ring with 4 waves x 64 samples
+    static const int variant = getenv("PTMI_NIF_VARIANT") ? atoi(getenv("PTMI_NIF_VARIANT")) : 0;
+    if (variant == 1) { hipLaunchKernelGGL((ptd::nif_kernel<HID, E, 2>), dim3(blocks), dim3(256), 0, h->stream, N); return PT_OK; }
+    if (variant == 2) return launch_nif_v2<HID, E, 2, 4>(h, N, blocks);
+    if (variant == 3) return launch_nif_v2<HID, E, 1, 8>(h, N, blocks);
+  }
 #endif
-#ifdef PTMI_DIAG_BUILD
-  if (launch_nif_diag<HID, E>(h, N, blocks)) return;
-  // A/B switch of the profiling build: 1 = weights straight from L2, 2 = LDS ring with 4 waves x 64 samples
-  static const int variant = getenv("PTMI_NIF_VARIANT") ? atoi(getenv("PTMI_NIF_VARIANT")) : 0;
-  if (variant == 1) { hipLaunchKernelGGL((ptd::nif_kernel<HID, E, 2>), dim3(blocks), dim3(256), 0, h->stream, N); return; }
-  if (variant == 2) { launch_nif_v2<HID, E, 2, 4>(h, N, blocks); return; }
-  if (variant == 3) { launch_nif_v2<HID, E, 1, 8>(h, N, blocks); return; }
-#endif
-  // v3 keeps the bias tiles of at most 8 layers resident in LDS; deeper networks take the v2 ring (layer 0 resident)
-  if (N.n_layers > (uint32_t)ptd::NifV3Geometry<HID, E, 8, 2>::MAX_LAYERS) launch_nif_v2<HID, E, 1, 8>(h, N, blocks);
-  else launch_nif_v3<HID, E, 8, 2>(h, N, blocks);
+  if (N.n_layers > (uint32_t)ptd::NifV3Geometry<HID, E, 8, TPS>::MAX_LAYERS) return launch_nif_v2<HID, E, 1, 8>(h, N, blocks);
+  return launch_nif_v3<HID, E, 8, TPS>(h, N, blocks);
+}
+
+template <int E>
+int launch_nif_e(pt_handle h, const ptd::NifParams& N, int blocks) {
+  switch (h->nif_hidden) {
+    case 32: return launch_nif_t<32, E>(h, N, blocks);
+    case 64: return launch_nif_t<64, E>(h, N, blocks);
+    case 96: return launch_nif_t<96, E>(h, N, blocks);
+    case 128: return launch_nif_t<128, E>(h, N, blocks);
+    case 160: return launch_nif_t<160, E>(h, N, blocks);
+    case 192: return launch_nif_t<192, E>(h, N, blocks);
+    case 224: return launch_nif_t<224, E>(h, N, blocks);
+    case 256: return launch_nif_t<256, E>(h, N, blocks);
+    case 288: return launch_nif_t<288, E>(h, N, blocks);
+    case 320: return launch_nif_t<320, E>(h, N, blocks);
+    default: break;
+  }
+  return fail(h, PT_ERR_UNSUPPORTED_MODEL, "no register-resident NIF kernel for hidden width " + std::to_string(h->nif_hidden));
 }
 
 #ifdef PTMI_DIAG_BUILD
 template <int HID, int E>
-void launch_nif_wide(pt_handle h, const ptd::NifParams& N, int blocks) {
+int launch_nif_wide(pt_handle h, const ptd::NifParams& N, int blocks) {
   constexpr int lds = (HID / 16) * 2 * 1024 + (ptd::kMaxRegions + 1 + 256) * 4;
-  static std::atomic<unsigned long long> attr_set{0};   // one bit per device; the host app drives devices from threads
-  if (!(attr_set.load(std::memory_order_relaxed) >> (h->cfg.device & 63) & 1ull)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ptd::nif_wide_kernel<HID, E>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set.fetch_or(1ull << (h->cfg.device & 63), std::memory_order_relaxed);
-  }
+  static std::atomic<unsigned long long> attr_set{0};
+  if (int rc = set_dynamic_lds(h, reinterpret_cast<const void*>(&ptd::nif_wide_kernel<HID, E>), lds, attr_set)) return rc;
   hipLaunchKernelGGL((ptd::nif_wide_kernel<HID, E>), dim3(blocks), dim3(256), lds, h->stream, N);
+  return PT_OK;
 }
 #endif
+
+template <int E>
+void launch_nifg_encode(pt_handle h, const ptd::NifParams& N, uint32_t tile0, uint32_t chunk) {
+  hipLaunchKernelGGL((ptd::nifg_encode_kernel<E>), dim3((chunk + 3u) / 4u), dim3(256), 0, h->stream, N, h->d_tile_start, tile0, chunk,
+                     h->d_gemm_feat);
+}
 
 // Wide networks, one launch per layer over chunks of the queue (pt_nif_gemm.h).  The number of queue tiles is only
 // known on the device, so chunks are launched up to the queue's capacity and those past its end return at once.
@@ -484,25 +583,19 @@ int launch_nif_gemm(pt_handle h, const ptd::NifParams& N) {
   const uint32_t H = (uint32_t)h->nif_hidden, KS = H / 16, IS = (uint32_t)h->nif_emb / 4, NT = H / 32, FB = NT / 8;
   const uint32_t n_layers = N.n_layers, chunk = h->gemm_chunk;
   if (!chunk) return fail(h, PT_ERR_NOT_READY, "wide-NIF buffers are not allocated");
-  static std::atomic<unsigned long long> attr_set{0};   // one bit per device; the host app drives devices from threads
-  if (!(attr_set.load(std::memory_order_relaxed) >> (h->cfg.device & 63) & 1ull)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ptd::nifg_layer_kernel<0>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, ptd::kGemmLdsBytes);
+  if (FB == 0 || NT % 8u) return fail(h, PT_ERR_UNSUPPORTED_MODEL, "layer-by-layer NIF path needs a hidden width that is a multiple of 256");
+  static std::atomic<unsigned long long> attr_set{0};
+  if (int rc = set_dynamic_lds(h, reinterpret_cast<const void*>(&ptd::nifg_layer_kernel<0>), ptd::kGemmLdsBytes, attr_set)) return rc;
 #ifdef PTMI_DIAG_BUILD
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ptd::nifg_layer_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, ptd::kGemmLdsBytes);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ptd::nifg_layer_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, ptd::kGemmLdsBytes);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ptd::nifg_layer_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, ptd::kGemmLdsBytes);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ptd::nifg_layer_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, ptd::kGemmLdsBytes);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ptd::nifg_layer_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, ptd::kGemmLdsBytes);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ptd::nifg_layer_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, ptd::kGemmLdsBytes);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ptd::nifg_layer_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, ptd::kGemmLdsBytes);
-#endif
-    attr_set.fetch_or(1ull << (h->cfg.device & 63), std::memory_order_relaxed);
-  }
-#ifdef PTMI_DIAG_BUILD
+  for (const void* fn : {reinterpret_cast<const void*>(&ptd::nifg_layer_kernel<1>), reinterpret_cast<const void*>(&ptd::nifg_layer_kernel<2>),
+                         reinterpret_cast<const void*>(&ptd::nifg_layer_kernel<3>), reinterpret_cast<const void*>(&ptd::nifg_layer_kernel<4>),
+                         reinterpret_cast<const void*>(&ptd::nifg_layer_kernel<7>), reinterpret_cast<const void*>(&ptd::nifg_layer_kernel<8>),
+                         reinterpret_cast<const void*>(&ptd::nifg_layer_kernel<16>)})
+    PT_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, ptd::kGemmLdsBytes));
   static const int gdiag = getenv("PTMI_GEMM_DIAG") ? atoi(getenv("PTMI_GEMM_DIAG")) : 0;   // timing-only ablations
 #endif
   hipLaunchKernelGGL(ptd::nifg_scan_kernel, dim3(1), dim3(256), 0, h->stream, N.region_count, N.n_regions, h->d_tile_start);
+  PT_HIP(hipGetLastError());
   const uint64_t max_tiles = (uint64_t)N.n_regions * ((N.region_cap + 31u) / 32u);
   uint32_t grid = ((uint32_t)h->n_cus / (8u * FB)) * 8u * FB;
   if (grid == 0) grid = 8u * FB;
@@ -516,11 +609,14 @@ int launch_nif_gemm(pt_handle h, const ptd::NifParams& N) {
   G.chunk_tiles = chunk;
   for (uint64_t tile0 = 0; tile0 < max_tiles; tile0 += chunk) {
     G.tile0 = (uint32_t)tile0;
-    const uint32_t enc_blocks = (chunk + 3u) / 4u;
-    if (h->nif_emb == 12)
-      hipLaunchKernelGGL((ptd::nifg_encode_kernel<12>), dim3(enc_blocks), dim3(256), 0, h->stream, N, h->d_tile_start, G.tile0, chunk, h->d_gemm_feat);
-    else
-      return fail(h, PT_ERR_UNSUPPORTED_MODEL, "wide NIFs are instantiated for embedding 12");
+    switch (h->nif_emb) {
+      case 4: launch_nifg_encode<4>(h, N, G.tile0, chunk); break;
+      case 8: launch_nifg_encode<8>(h, N, G.tile0, chunk); break;
+      case 12: launch_nifg_encode<12>(h, N, G.tile0, chunk); break;
+      case 16: launch_nifg_encode<16>(h, N, G.tile0, chunk); break;
+      default: return fail(h, PT_ERR_UNSUPPORTED_MODEL, "unsupported embedding dimension");
+    }
+    PT_HIP(hipGetLastError());
     for (uint32_t l = 0; l + 1 < n_layers; ++l) {
       const bool concat = (N.concat_mask >> l) & 1u;
       G.piece_base = N.piece_base[l];
@@ -541,6 +637,7 @@ int launch_nif_gemm(pt_handle h, const ptd::NifParams& N) {
       if (gdiag == 16) { hipLaunchKernelGGL(ptd::nifg_layer_kernel<16>, dim3(grid), dim3(512), ptd::kGemmLdsBytes, h->stream, G); continue; }
 #endif
       hipLaunchKernelGGL(ptd::nifg_layer_kernel<0>, dim3(grid), dim3(512), ptd::kGemmLdsBytes, h->stream, G);
+      PT_HIP(hipGetLastError());
     }
     const uint32_t l = n_layers - 1;
     G.piece_base = N.piece_base[l];
@@ -552,39 +649,31 @@ int launch_nif_gemm(pt_handle h, const ptd::NifParams& N) {
     G.act_in = h->d_gemm_act[(l + 1u) & 1u];
     G.act_out = nullptr;
     hipLaunchKernelGGL(ptd::nifg_head_kernel, dim3((chunk + 15u) / 16u), dim3(256), 0, h->stream, N, G, h->d_tile_start);
+    PT_HIP(hipGetLastError());
   }
   return PT_OK;
 }
 
 int launch_nif(pt_handle h, const ptd::NifParams& N, int blocks) {
-  if (h->nif_emb == 12 && (h->nif_hidden == 1024 || h->nif_hidden == 512)) {
+  if (h->nif_gemm) {
 #ifdef PTMI_DIAG_BUILD
     // A/B switch of the profiling build: the fused 64-sample kernel with activations in LDS
     static const bool fused = getenv("PTMI_NIF_WIDE") && !strcmp(getenv("PTMI_NIF_WIDE"), "fused");
-    if (fused) {
-      if (h->nif_hidden == 1024) launch_nif_wide<1024, 12>(h, N, blocks); else launch_nif_wide<512, 12>(h, N, blocks);
-      return PT_OK;
+    if (fused && h->nif_emb == 12) {
+      if (h->nif_hidden == 1024) return launch_nif_wide<1024, 12>(h, N, blocks);
+      if (h->nif_hidden == 512) return launch_nif_wide<512, 12>(h, N, blocks);
     }
 #endif
     return launch_nif_gemm(h, N);
   }
-  if (h->nif_emb == 12) {
-    switch (h->nif_hidden) {
-      case 64: launch_nif_t<64, 12>(h, N, blocks); return PT_OK;
-      case 128: launch_nif_t<128, 12>(h, N, blocks); return PT_OK;
-      case 256: launch_nif_t<256, 12>(h, N, blocks); return PT_OK;
-      case 320: launch_nif_t<320, 12>(h, N, blocks); return PT_OK;
-      default: break;
-    }
+  switch (h->nif_emb) {
+    case 4: return launch_nif_e<4>(h, N, blocks);
+    case 8: return launch_nif_e<8>(h, N, blocks);
+    case 12: return launch_nif_e<12>(h, N, blocks);
+    case 16: return launch_nif_e<16>(h, N, blocks);
+    default: break;
   }
-  if (h->nif_emb == 4 && h->nif_hidden == 64) { launch_nif_t<64, 4>(h, N, blocks); return PT_OK; }
-  return fail(h, PT_ERR_UNSUPPORTED_MODEL, "no MFMA kernel instantiated for this NIF shape");
-}
-
-bool nif_shape_supported(uint32_t hidden, uint32_t emb) {
-  if (emb == 12 && (hidden == 64 || hidden == 128 || hidden == 256 || hidden == 320 || hidden == 512 || hidden == 1024)) return true;
-  if (emb == 4 && hidden == 64) return true;
-  return false;
+  return fail(h, PT_ERR_UNSUPPORTED_MODEL, "unsupported embedding dimension");
 }
 
 void free_batch_buffers(pt_handle h) {
@@ -600,8 +689,8 @@ void free_batch_buffers(pt_handle h) {
 
 hipEvent_t get_event(pt_handle h, size_t i) {
   while (h->events.size() <= i) {
-    hipEvent_t e;
-    (void)hipEventCreate(&e);
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
     h->events.push_back(e);
   }
   return h->events[i];
@@ -723,58 +812,78 @@ int pt_upload_nif(pt_handle h, const pt_layer* layers, uint32_t n_layers, uint32
   std::vector<HostLayer> L(n_layers);
   uint64_t flops = 0;
   for (uint32_t l = 0; l < n_layers; ++l) {
-    if (layers[l].dtype != PT_DTYPE_F16) return fail(h, PT_ERR_UNSUPPORTED_MODEL, "only fp16 NIF weights are supported");
+    if (layers[l].dtype != PT_DTYPE_F16 && layers[l].dtype != PT_DTYPE_F32)
+      return fail(h, PT_ERR_UNSUPPORTED_MODEL, "NIF weights must be float16 or float32");
     if (!layers[l].kernel || layers[l].rows == 0 || layers[l].cols == 0) return fail(h, PT_ERR_INVALID_ARGUMENT, "empty layer kernel");
     L[l].rows = layers[l].rows;
     L[l].cols = layers[l].cols;
     L[l].relu = layers[l].relu != 0;
-    const uint16_t* kp = static_cast<const uint16_t*>(layers[l].kernel);
-    L[l].kernel.assign(kp, kp + (size_t)L[l].rows * L[l].cols);
-    if (layers[l].bias) {
-      const uint16_t* bp = static_cast<const uint16_t*>(layers[l].bias);
-      L[l].bias.assign(bp, bp + L[l].cols);
+    const size_t count = (size_t)L[l].rows * L[l].cols;
+    if (layers[l].dtype == PT_DTYPE_F16) {
+      const uint16_t* kp = static_cast<const uint16_t*>(layers[l].kernel);
+      L[l].kernel.assign(kp, kp + count);
+      if (layers[l].bias) {
+        const uint16_t* bp = static_cast<const uint16_t*>(layers[l].bias);
+        L[l].bias.assign(bp, bp + L[l].cols);
+      }
+    } else {
+      // float32 H5 weights (Hdf5Model.cpp:109-133 accepts them; the reference then runs the layer in float): rounded to
+      // binary16 (RNE) here, the MFMA path computes in fp16 with fp32 accumulation -- DESIGN.md section 2, "fp32 weights"
+      const float* kp = static_cast<const float*>(layers[l].kernel);
+      L[l].kernel.resize(count);
+      for (size_t i = 0; i < count; ++i) L[l].kernel[i] = host_f2h(kp[i]);
+      if (layers[l].bias) {
+        const float* bp = static_cast<const float*>(layers[l].bias);
+        L[l].bias.resize(L[l].cols);
+        for (uint32_t i = 0; i < L[l].cols; ++i) L[l].bias[i] = host_f2h(bp[i]);
+      }
     }
     flops += 2ull * L[l].rows * L[l].cols + (layers[l].bias ? L[l].cols : 0);  // NifModel.cpp:129-133
   }
-  const uint32_t hidden = L[0].cols;
-  if (!nif_shape_supported(hidden, embedding_dim))
-    return fail(h, PT_ERR_UNSUPPORTED_MODEL, "NIF shape (hidden " + std::to_string(hidden) + ", embedding " +
-                                                 std::to_string(embedding_dim) + ") has no MFMA kernel in this build");
+  std::vector<HostLayer> padded;
+  NifPlan plan;
+  int rc = normalize_nif(h, L, embedding_dim, padded, plan);
+  if (rc) return rc;
   std::vector<uint16_t> wpack, bpack;
   ptd::NifParams N;
+  bool m16 = false;
+#ifdef PTMI_DIAG_BUILD
   // A/B switch of the profiling build: PTMI_NIF_KERNEL=v4 packs for the 16x16x32 kernel (pt_nif16.h).  Measured equal
   // to v3 in NIF time within 1-2 %, but its 230 VGPRs leave no room for the trace kernel's waves beside it, so
   // the step is 1.5 % slower end to end (profiles/r01_c_nif_ablation.txt); v3 stays the product kernel.
-  bool m16 = false;
-#ifdef PTMI_DIAG_BUILD
-  if (const char* k = getenv("PTMI_NIF_KERNEL")) m16 = strcmp(k, "v4") == 0 && hidden <= 320 && n_layers <= 8;
+  if (const char* k = getenv("PTMI_NIF_KERNEL")) m16 = strcmp(k, "v4") == 0 && plan.Hp == 320 && plan.Ep == 12 && n_layers <= 8;
+  rc = m16 ? pack_nif16(h, padded, plan.Ep, wpack, bpack, N) : pack_nif(h, padded, plan.Ep, wpack, bpack, N);
+#else
+  rc = pack_nif(h, padded, plan.Ep, wpack, bpack, N);
 #endif
-  int rc = m16 ? pack_nif16(h, L, embedding_dim, wpack, bpack, N) : pack_nif(h, L, embedding_dim, wpack, bpack, N);
   if (rc) return rc;
   PT_HIP(hipSetDevice(h->cfg.device));
   PT_HIP(hipStreamSynchronize(h->stream));
   if (h->d_wpack) PT_HIP(hipFree(h->d_wpack));
   if (h->d_bpack) PT_HIP(hipFree(h->d_bpack));
   h->d_wpack = nullptr; h->d_bpack = nullptr;
+  h->nif_valid = false;
   PT_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_wpack), wpack.size() * 2));
   PT_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_bpack), bpack.size() * 2));
   PT_HIP(hipMemcpy(h->d_wpack, wpack.data(), wpack.size() * 2, hipMemcpyHostToDevice));
   PT_HIP(hipMemcpy(h->d_bpack, bpack.data(), bpack.size() * 2, hipMemcpyHostToDevice));
   N.wpack = h->d_wpack;
   N.bpack = h->d_bpack;
+  N.n_freq = plan.E;
   N.max = max;
   N.mean0 = mean[0]; N.mean1 = mean[1]; N.mean2 = mean[2];
   N.log_tonemap = log_tonemap;
-  if (hidden >= 512) {   // wide network: chunk buffers of the layer-by-layer path
+  if (plan.gemm) {   // wide network: chunk buffers of the layer-by-layer path
     uint32_t chunk = 4096;
 #ifdef PTMI_DIAG_BUILD
     if (const char* c = getenv("PTMI_GEMM_CHUNK")) chunk = (uint32_t)atoi(c) / 8u * 8u;   // chunk-size sweep of the profiling build
     if (chunk == 0) chunk = 8;
 #endif
-    const size_t act_bytes = (size_t)chunk * (hidden / 16) * 1024, feat_bytes = (size_t)chunk * (embedding_dim / 4) * 1024 + 1024;   // + one piece: the paired loader reads one past an odd k-step count
+    const size_t act_bytes = (size_t)chunk * (plan.Hp / 16) * 1024, feat_bytes = (size_t)chunk * (plan.Ep / 4) * 1024 + 1024;   // + one piece: the paired loader reads one past an odd k-step count
     for (int i = 0; i < 2; ++i) {
       if (h->d_gemm_act[i]) PT_HIP(hipFree(h->d_gemm_act[i]));
       h->d_gemm_act[i] = nullptr;
+      h->gemm_chunk = 0;
       PT_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_gemm_act[i]), act_bytes));
     }
     if (h->d_gemm_feat) PT_HIP(hipFree(h->d_gemm_feat));
@@ -784,8 +893,9 @@ int pt_upload_nif(pt_handle h, const pt_layer* layers, uint32_t n_layers, uint32
     h->gemm_chunk = chunk;
   }
   h->nif = N;
-  h->nif_hidden = (int)hidden;
-  h->nif_emb = (int)embedding_dim;
+  h->nif_hidden = (int)plan.Hp;
+  h->nif_emb = (int)plan.Ep;
+  h->nif_gemm = plan.gemm;
   h->nif_m16 = m16;
   h->nif_flops = flops;
   h->nif_valid = true;
@@ -804,6 +914,10 @@ int pt_set_constant_env(pt_handle h, const float rgb[3]) {
 int pt_set_render_settings(pt_handle h, uint64_t seed, float aa, float fov, float azimuth, uint32_t spp) {
   if (!h) return PT_ERR_INVALID_ARGUMENT;
   if (spp == 0) return fail(h, PT_ERR_INVALID_ARGUMENT, "samples_per_step must be > 0");
+  // TraceRecord::sampleCount is uint16 (TraceRecord.hpp:10) and the host divides by it (AccumulatedImage.cpp:69-71):
+  // more than 65535 samples per step would wrap it (to 0 at 65536).  pathLength (:11) is uint16 too and is allowed
+  // to wrap as in the reference (samples_per_step x max_path_length may exceed 65535); stats.segments is exact.
+  if (spp > 65535u) return fail(h, PT_ERR_INVALID_ARGUMENT, "samples_per_step must be <= 65535 (TraceRecord::sampleCount is uint16)");
   if (!(fov > 0.f && fov < 3.14159f)) return fail(h, PT_ERR_INVALID_ARGUMENT, "fov must be in (0, pi) radians");
   if (!h->settings_valid || seed != h->seed) h->sample_cursor = 0;
   h->seed = seed; h->aa_scale = aa; h->fov = fov; h->azimuth = azimuth; h->samples_per_step = spp;
@@ -827,17 +941,14 @@ int pt_setup(pt_handle h, const pt_trace_record* work, size_t n) {
   return PT_OK;
 }
 
-int pt_path_trace(pt_handle h) {
-  if (!h) return PT_ERR_INVALID_ARGUMENT;
-  if (!h->settings_valid) return fail(h, PT_ERR_NOT_READY, "pt_set_render_settings has not been called");
-  if (!h->env_const && !h->nif_valid) return fail(h, PT_ERR_NOT_READY, "no environment: call pt_upload_nif or pt_set_constant_env");
-  PT_HIP(hipSetDevice(h->cfg.device));
-  memset(&h->stats, 0, sizeof(h->stats));
-  h->stats.nif_flops_per_sample = h->env_const ? 0 : h->nif_flops;
-  const uint32_t n = h->n_items;
-  if (n == 0) return PT_OK;
-  PT_HIP(hipMemsetAsync(h->d_counters, 0, 2 * sizeof(unsigned long long), h->stream));
+// Enqueue the whole path_trace program on the three streams.  Returns at the first failing call; the caller drains the
+// streams either way, so a failure in the middle of the batch loop never leaves kernels running on buffers the host
+// is about to reuse or free.
+struct StageSpan { size_t a, b; int kind; };   // event pair around one stage of one batch: 0 trace, 1 NIF, 2 accumulate
 
+static int enqueue_path_trace(pt_handle h, std::vector<StageSpan>& spans, size_t& e_begin_i, size_t& e_end_i) {
+  const uint32_t n = h->n_items;
+  PT_HIP(hipMemsetAsync(h->d_counters, 0, 2 * sizeof(unsigned long long), h->stream));
   ptd::TraceParams P;
   fill_trace_params(h, P);
   P.n_items = n;
@@ -846,11 +957,11 @@ int pt_path_trace(pt_handle h) {
   // buffer set b&1 is reused by T(b+2) once A(b) has consumed it.  The A(b) are ordered among themselves (one
   // stream), which keeps every pixel's fp32 sum in iteration order.
   size_t ev = 0;
+  e_begin_i = ev;
   hipEvent_t e_begin = get_event(h, ev++);
+  if (!e_begin) return fail(h, PT_ERR_HIP, "hipEventCreate failed");
   PT_HIP(hipEventRecord(e_begin, h->stream));
   PT_HIP(hipStreamWaitEvent(h->trace_stream, e_begin, 0));   // counters memset and earlier work on `stream`
-  struct Span { size_t a, b; int kind; };
-  std::vector<Span> spans;
   uint32_t done = 0, batch = 0;
   while (done < h->samples_per_step) {
     const uint32_t iters = std::min(h->iters_per_batch, h->samples_per_step - done);
@@ -864,10 +975,12 @@ int pt_path_trace(pt_handle h) {
     bind_batch(P, B);
 
     hipEvent_t t0 = get_event(h, ev), t1 = get_event(h, ev + 1), n0 = get_event(h, ev + 2), n1 = get_event(h, ev + 3),
-               a1 = get_event(h, ev + 4);
+               a1 = get_event(h, ev + 4), a0 = get_event(h, ev + 5);
+    if (!t0 || !t1 || !n0 || !n1 || !a1 || !a0) return fail(h, PT_ERR_HIP, "hipEventCreate failed");
     if (batch >= 2) PT_HIP(hipStreamWaitEvent(h->trace_stream, B.accumulated, 0));
     PT_HIP(hipEventRecord(t0, h->trace_stream));
     hipLaunchKernelGGL(ptd::trace_kernel, dim3(g.blocks), dim3(ptd::kTraceBlock), 0, h->trace_stream, P);
+    PT_HIP(hipGetLastError());
     PT_HIP(hipEventRecord(t1, h->trace_stream));
     PT_HIP(hipEventRecord(B.traced, h->trace_stream));
     spans.push_back({ev, ev + 1, 0});
@@ -881,17 +994,16 @@ int pt_path_trace(pt_handle h) {
       N.region_cap = g.region_cap;
       N.rad_r = B.rad_r; N.rad_g = B.rad_g; N.rad_b = B.rad_b;
       N.out_bgr = nullptr;
-      int rc = launch_nif(h, N, h->n_cus);
-      if (rc) return rc;
+      if (int rc = launch_nif(h, N, h->n_cus)) return rc;
       spans.push_back({ev + 2, ev + 3, 1});
       h->stats.nif_launches += 1;
     }
     PT_HIP(hipEventRecord(n1, h->stream));
-    hipEvent_t a0 = get_event(h, ev + 5);
     PT_HIP(hipStreamWaitEvent(h->acc_stream, n1, 0));
     PT_HIP(hipEventRecord(a0, h->acc_stream));
     hipLaunchKernelGGL(ptd::accumulate_kernel, dim3((n + 255) / 256), dim3(256), 0, h->acc_stream, n, iters, B.plen, B.rad_r,
                        B.rad_g, B.rad_b, h->acc, h->d_counters);
+    PT_HIP(hipGetLastError());
     PT_HIP(hipEventRecord(a1, h->acc_stream));
     PT_HIP(hipEventRecord(B.accumulated, h->acc_stream));
     spans.push_back({ev + 5, ev + 4, 2});
@@ -902,14 +1014,35 @@ int pt_path_trace(pt_handle h) {
     batch += 1;
   }
   hipEvent_t e_acc = get_event(h, ev++);
+  if (!e_acc) return fail(h, PT_ERR_HIP, "hipEventCreate failed");
   PT_HIP(hipEventRecord(e_acc, h->acc_stream));
   PT_HIP(hipStreamWaitEvent(h->stream, e_acc, 0));          // later work on `stream` sees the accumulated film
+  e_end_i = ev;
   hipEvent_t e_end = get_event(h, ev++);
+  if (!e_end) return fail(h, PT_ERR_HIP, "hipEventCreate failed");
   PT_HIP(hipEventRecord(e_end, h->stream));
-  PT_HIP(hipGetLastError());
-  PT_HIP(hipStreamSynchronize(h->stream));
-  PT_HIP(hipStreamSynchronize(h->trace_stream));
-  PT_HIP(hipStreamSynchronize(h->acc_stream));
+  return PT_OK;
+}
+
+int pt_path_trace(pt_handle h) {
+  if (!h) return PT_ERR_INVALID_ARGUMENT;
+  if (!h->settings_valid) return fail(h, PT_ERR_NOT_READY, "pt_set_render_settings has not been called");
+  if (!h->env_const && !h->nif_valid) return fail(h, PT_ERR_NOT_READY, "no environment: call pt_upload_nif or pt_set_constant_env");
+  PT_HIP(hipSetDevice(h->cfg.device));
+  memset(&h->stats, 0, sizeof(h->stats));
+  h->stats.nif_flops_per_sample = h->env_const ? 0 : h->nif_flops;
+  const uint32_t n = h->n_items;
+  if (n == 0) return PT_OK;
+
+  std::vector<StageSpan> spans;
+  size_t e_begin_i = 0, e_end_i = 0;
+  const int rc = enqueue_path_trace(h, spans, e_begin_i, e_end_i);
+  // Drain all three streams whether or not the enqueue succeeded (a kernel fault surfaces here as well).
+  const hipError_t s0 = hipStreamSynchronize(h->stream), s1 = hipStreamSynchronize(h->trace_stream),
+                   s2 = hipStreamSynchronize(h->acc_stream);
+  if (rc) return rc;   // h->error names the failing call
+  for (hipError_t e : {s0, s1, s2})
+    if (e != hipSuccess) return fail(h, PT_ERR_HIP, std::string("path_trace: ") + hipGetErrorString(e));
   h->sample_cursor += h->samples_per_step;
 
   unsigned long long counters[2] = {0, 0};
@@ -917,7 +1050,7 @@ int pt_path_trace(pt_handle h) {
   h->stats.paths = (uint64_t)n * h->samples_per_step;
   h->stats.segments = counters[0];
   h->stats.escaped = counters[1];
-  for (const Span& s : spans) {
+  for (const StageSpan& s : spans) {
     float ms = 0.f;
     PT_HIP(hipEventElapsedTime(&ms, h->events[s.a], h->events[s.b]));
     if (s.kind == 0) h->stats.path_trace_ms += ms;
@@ -925,7 +1058,7 @@ int pt_path_trace(pt_handle h) {
     else h->stats.accumulate_ms += ms;
   }
   float total_ms = 0.f;
-  PT_HIP(hipEventElapsedTime(&total_ms, e_begin, e_end));
+  PT_HIP(hipEventElapsedTime(&total_ms, h->events[e_begin_i], h->events[e_end_i]));
   h->stats.total_ms = total_ms;
   return PT_OK;
 }

@@ -74,7 +74,7 @@ NifModel::Data::Data(const std::string& metaFile) : metaData(metaFile) {
 NifModel::Data::Data(const std::string& weightFile, const std::string& metaFile) : Data(metaFile) { setupModel(weightFile); }
 
 // converted.ptnif: "PTNIF1\0\0", u32 n_layers, u32 embedding_dim, then per layer
-// u32 rows, cols, dtype (0 = float16), relu, has_bias followed by the kernel bytes [rows][cols] and bias bytes.
+// u32 rows, cols, dtype (0 = float16, 1 = float32), relu, has_bias followed by the kernel bytes [rows][cols] and bias bytes.
 void NifModel::Data::setupModel(const std::string& weightFile) {
   if (weightFile.size() > 5 && (weightFile.rfind(".hdf5") == weightFile.size() - 5 || weightFile.rfind(".h5") == weightFile.size() - 3)) {
     // the reference's own asset format: NifModel.cpp:51-85 on top of Hdf5Model
@@ -96,21 +96,30 @@ void NifModel::Data::setupModel(const std::string& weightFile) {
   char magic[8];
   f.read(magic, 8);
   if (std::memcmp(magic, "PTNIF1\0\0", 8) != 0) throw std::runtime_error("'" + weightFile + "' is not a PTNIF1 file");
+  f.seekg(0, std::ios::end);
+  const std::uint64_t fileSize = (std::uint64_t)f.tellg();
+  f.seekg(8, std::ios::beg);
   std::uint32_t n = 0, emb = 0;
   f.read((char*)&n, 4);
   f.read((char*)&emb, 4);
+  if (!f || n == 0 || n > 16) throw std::runtime_error("'" + weightFile + "': layer count must be in 1..16");
   if (emb != metaData.embeddingDimension) throw std::runtime_error("embedding dimension of weights and metadata differ");
   for (std::uint32_t i = 0; i < n; ++i) {
     std::uint32_t hdr[5];
     f.read((char*)hdr, sizeof(hdr));
-    if (!f || hdr[2] != 0) throw std::runtime_error("Only float16 weights are supported.");
-    layers.emplace_back(std::vector<std::size_t>{hdr[0], hdr[1]}, "float16", hdr[3] ? "relu" : "none",
+    if (!f) throw std::runtime_error("Truncated NIF weight file '" + weightFile + "'");
+    if (hdr[2] > 1) throw std::runtime_error("Only float16 and float32 weights are supported.");
+    const std::size_t esz = hdr[2] == 0 ? 2 : 4;
+    // sizes come from the file: bound them by what the file can hold before allocating
+    if (hdr[0] == 0 || hdr[1] == 0 || (std::uint64_t)hdr[0] * hdr[1] * esz > fileSize)
+      throw std::runtime_error("'" + weightFile + "': layer " + std::to_string(i) + " has an impossible shape");
+    layers.emplace_back(std::vector<std::size_t>{hdr[0], hdr[1]}, hdr[2] == 0 ? "float16" : "float32", hdr[3] ? "relu" : "none",
                         "dense_" + std::to_string(i));
     auto& l = layers.back();
-    l.kernel.data.resize((std::size_t)hdr[0] * hdr[1] * 2);
+    l.kernel.data.resize((std::size_t)hdr[0] * hdr[1] * esz);
     f.read((char*)l.kernel.data.data(), l.kernel.data.size());
     if (hdr[4]) {
-      l.bias.data.resize((std::size_t)hdr[1] * 2);
+      l.bias.data.resize((std::size_t)hdr[1] * esz);
       f.read((char*)l.bias.data.data(), l.bias.data.size());
     }
     if (!f) throw std::runtime_error("Truncated NIF weight file '" + weightFile + "'");
@@ -167,17 +176,22 @@ void NifModel::analyseModel(std::size_t sampleCount) const {
 
 void NifModel::upload(pt_handle device) const {
   std::vector<pt_layer> ls;
+  std::size_t converted = 0;
   for (const auto& l : data->getLayers()) {
     pt_layer p{};
     p.rows = (std::uint32_t)l.kernel.shape[0];
     p.cols = (std::uint32_t)l.kernel.shape[1];
     p.kernel = l.kernel.data.data();
     p.bias = l.hasBias() ? l.bias.data.data() : nullptr;
-    p.dtype = PT_DTYPE_F16;
     p.relu = l.activationFunction == "relu";
-    if (l.kernel.type != "float16") throw std::runtime_error("Only float16 NIF weights are supported on this device.");
+    // NifModel.cpp:58-60 accepts float16 and float32 layers; the MFMA path computes in fp16, so float32 weights are
+    // rounded to binary16 (RNE) by pt_upload_nif -- a documented deviation
+    if (l.kernel.type == "float16") p.dtype = PT_DTYPE_F16;
+    else if (l.kernel.type == "float32") { p.dtype = PT_DTYPE_F32; converted += 1; }
+    else throw std::runtime_error("Unsupported NIF weight type '" + l.kernel.type + "' (expected float16 or float32).");
     ls.push_back(p);
   }
+  if (converted) pt_log::info_("NIF {}: {} float32 layers rounded to float16 for the MFMA path", name, converted);
   const auto& m = data->getMetaData();
   if (pt_upload_nif(device, ls.data(), (std::uint32_t)ls.size(), (std::uint32_t)m.embeddingDimension, m.max, m.mean.data(),
                     m.logToneMap ? 1 : 0))

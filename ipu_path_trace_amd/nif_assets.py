@@ -58,28 +58,37 @@ def folded_mean(meta=URBAN_ALLEY_META):
     return [float(np.float32(np.float32(m) - eps)) for m in meta["mean"]]
 
 
-def synthetic_nif(hidden=320, layer_count=6, embedding_dim=12, seed=2024, bias_scale=0.05):
-    """Return [(kernel fp16 [in,out], bias fp16 [out], relu)], Keras-Dense layout (NifModel.cpp:375-401).
+def synthetic_nif(hidden=320, layer_count=6, embedding_dim=12, seed=2024, bias_scale=0.05, dtype=np.float16,
+                  widths=None, skips=None):
+    """Return [(kernel [in,out], bias [out], relu)], Keras-Dense layout (NifModel.cpp:375-401).
 
     Architecture as inferred in SURVEY.md row A9: `layer_count` hidden ReLU layers of width `hidden`,
     the Fourier-feature input re-concatenated at the middle layer (the shape mismatch that
-    NifModel.cpp:305-308 detects), and a linear 3-channel head.
+    NifModel.cpp:305-308 detects), and a linear 3-channel head.  `widths` gives every hidden layer its own
+    width and `skips` the set of layers that take concat(x, input) instead (the reference builds whatever
+    stack the H5 describes, NifModel.cpp:295-326); `dtype` float32 yields a float32-variable model
+    (Hdf5Model.cpp:109-133 accepts both).
     """
     rng = np.random.Generator(np.random.Philox(seed))
     in_dim = 4 * embedding_dim
-    skip = layer_count // 2
+    if widths is None:
+        widths = [hidden] * layer_count
+    if skips is None:
+        skips = {len(widths) // 2}
     layers = []
     fan_in = in_dim
-    for l in range(layer_count):
-        if l == skip:
+    for l, width in enumerate(widths):
+        if l in skips and l > 0:
             fan_in += in_dim
-        k = rng.standard_normal((fan_in, hidden), dtype=np.float32) * np.float32(np.sqrt(2.0 / fan_in))
-        b = rng.standard_normal(hidden, dtype=np.float32) * np.float32(bias_scale)
-        layers.append((k.astype(np.float16), b.astype(np.float16), True))
-        fan_in = hidden
+        k = rng.standard_normal((fan_in, width), dtype=np.float32) * np.float32(np.sqrt(2.0 / fan_in))
+        b = rng.standard_normal(width, dtype=np.float32) * np.float32(bias_scale)
+        layers.append((k.astype(dtype), b.astype(dtype), True))
+        fan_in = width
+    if len(widths) in skips:
+        fan_in += in_dim
     k = rng.standard_normal((fan_in, 3), dtype=np.float32) * np.float32(0.25 * np.sqrt(2.0 / fan_in))
     b = rng.standard_normal(3, dtype=np.float32) * np.float32(bias_scale)
-    layers.append((k.astype(np.float16), b.astype(np.float16), False))
+    layers.append((k.astype(dtype), b.astype(dtype), False))
     return layers
 
 
@@ -97,19 +106,20 @@ def write_ptnif(path, layers, embedding_dim):
     """Flat side-car weight file read by the C++ host (ipu_path_trace_amd/host/NifModel.cpp: setupModel).
 
     Stands in for <assets>/converted.hdf5 (reference src/keras/Hdf5Model.cpp:62-87), which needs libhdf5.
-    Layout: b"PTNIF1\0\0", u32 n_layers, u32 embedding_dim, then per layer u32 rows, cols, dtype (0 = float16),
-    relu, has_bias followed by the raw kernel bytes [rows][cols] and the bias bytes [cols].
+    Layout: b"PTNIF1\0\0", u32 n_layers, u32 embedding_dim, then per layer u32 rows, cols, dtype (0 = float16,
+    1 = float32), relu, has_bias followed by the raw kernel bytes [rows][cols] and the bias bytes [cols].
     """
     import struct
     with open(path, "wb") as f:
         f.write(b"PTNIF1\0\0")
         f.write(struct.pack("<II", len(layers), embedding_dim))
         for k, b, relu in layers:
-            k = np.ascontiguousarray(k, dtype=np.float16)
-            f.write(struct.pack("<IIIII", k.shape[0], k.shape[1], 0, int(bool(relu)), int(b is not None)))
+            dt = np.float32 if np.asarray(k).dtype == np.float32 else np.float16
+            k = np.ascontiguousarray(k, dtype=dt)
+            f.write(struct.pack("<IIIII", k.shape[0], k.shape[1], int(dt == np.float32), int(bool(relu)), int(b is not None)))
             f.write(k.tobytes())
             if b is not None:
-                f.write(np.ascontiguousarray(b, dtype=np.float16).tobytes())
+                f.write(np.ascontiguousarray(b, dtype=dt).tobytes())
 
 
 def write_metadata(path, meta=URBAN_ALLEY_META):

@@ -17,7 +17,7 @@ assert PATH_DTYPE.itemsize == 48
 
 AA_NORMAL, AA_UNIFORM, AA_TRUNCATED_NORMAL = 0, 1, 2
 SAMPLES_HALF, SAMPLES_FLOAT = 0, 1
-DTYPE_F16 = 0
+DTYPE_F16, DTYPE_F32 = 0, 1
 
 EXPORTS = ["pt_abi_version", "pt_create", "pt_destroy", "pt_last_error", "pt_upload_nif", "pt_set_constant_env",
            "pt_set_render_settings", "pt_setup", "pt_path_trace", "pt_read_results", "pt_get_stats",
@@ -148,15 +148,18 @@ class Renderer:
         arr = (Layer * len(layers))()
         keep = []
         for i, (k, b, relu) in enumerate(layers):
-            k = np.ascontiguousarray(k, dtype=np.float16)
+            # float32 kernels are handed over as float32 (the library rounds them to binary16, as documented in
+            # include/ptmi.h); everything else is passed as float16, the type the reference's shipped NIFs use
+            dt = np.float32 if np.asarray(k).dtype == np.float32 else np.float16
+            k = np.ascontiguousarray(k, dtype=dt)
             keep.append(k)
             arr[i].rows, arr[i].cols = k.shape
             arr[i].kernel = k.ctypes.data
             if b is not None:
-                b = np.ascontiguousarray(b, dtype=np.float16)
+                b = np.ascontiguousarray(b, dtype=dt)
                 keep.append(b)
                 arr[i].bias = b.ctypes.data
-            arr[i].dtype = DTYPE_F16
+            arr[i].dtype = DTYPE_F32 if dt == np.float32 else DTYPE_F16
             arr[i].relu = int(bool(relu))
         mean = (C.c_float * 3)(*[float(x) for x in mean_folded])
         self._check(self._lib.pt_upload_nif(self.handle, arr, len(layers), embedding_dim, float(max_value), mean,

@@ -113,6 +113,10 @@ def test_clear_accumulators_and_device_hdr_export(ptmi_lib):
     r.read_results(rec)
     assert np.all(rec["r"] == 0) and np.all(rec["sampleCount"] == 0) and np.all(rec["pathLength"] == 0)
     assert rec["u"][5] == 5                                        # coordinates are kept
+    out.fill_(7.0)
+    r.export_hdr_device(out.data_ptr(), rec.size)                  # no samples yet: exports 0, not 0/0
+    r.synchronize()
+    assert torch.count_nonzero(out).item() == 0
     r.close()
 
 

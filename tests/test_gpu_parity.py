@@ -199,7 +199,10 @@ def test_errors_are_reported(ptmi_lib):
     r.init_render_settings(samples_per_step=1)
     with pytest.raises(ptmi_lib.PtError):
         r.path_trace()  # no environment
-    bad = nif_assets.synthetic_nif(hidden=96, layer_count=2)
+    bad = nif_assets.synthetic_nif(hidden=96, layer_count=2)[:-1]
     with pytest.raises(ptmi_lib.PtError):
-        r.init_nif_weights(bad, 12, 1.0, [0, 0, 0])  # hidden size without an MFMA kernel
+        r.init_nif_weights(bad, 12, 1.0, [0, 0, 0])  # no 3-channel head
+    with pytest.raises(ptmi_lib.PtError) as e:
+        r.init_render_settings(samples_per_step=65536)   # TraceRecord::sampleCount is uint16 (TraceRecord.hpp:10)
+    assert e.value.code == -1
     r.close()

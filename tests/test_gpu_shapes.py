@@ -1,0 +1,110 @@
+"""NIF shapes beyond the shipped 6x320 / embedding 12 (reference: NifModel.cpp:295-326 builds whatever Dense stack
+the H5 describes; Hdf5Model.cpp:109-133 accepts float16 and float32 variables).  Same stated tolerance as
+test_gpu_parity.py: decoded radiance within 2e-2 relative of the oracle, median below 2e-3.
+
+Parity of these shapes is UNPINNED by the reference (it ships one metadata file and no weights): the checker is
+the oracle's independent fp32 restatement of the same rounding points.
+"""
+import numpy as np
+import pytest
+
+from ipu_path_trace_amd import nif_assets
+
+pytestmark = pytest.mark.gpu
+
+NIF_RTOL_MAX = 2e-2
+NIF_RTOL_MEDIAN = 2e-3
+META = nif_assets.URBAN_ALLEY_META
+
+
+def _check(O, ptmi, L, emb, sizes=(1, 65, 3000), seed=5):
+    mean = nif_assets.folded_mean()
+    onif = O.Nif([(np.asarray(k, dtype=np.float16), None if b is None else np.asarray(b, dtype=np.float16), relu)
+                  for k, b, relu in L], emb, META["max"], mean)
+    r = ptmi.Renderer(64, 64)
+    r.init_nif_weights(L, emb, META["max"], mean)
+    rng = np.random.default_rng(seed)
+    for n in sizes:
+        u = rng.random(n, dtype=np.float32)
+        v = rng.random(n, dtype=np.float32)
+        got = r.nif_infer(u, v)
+        ref = onif.infer(u, v)
+        assert np.isfinite(got).all()
+        rel = np.abs(got - ref) / np.abs(ref)
+        assert rel.max() < NIF_RTOL_MAX, (n, rel.max())
+        if n > 100:
+            assert np.median(rel) < NIF_RTOL_MEDIAN
+    r.close()
+
+
+@pytest.mark.parametrize("emb", [4, 8, 12, 16])
+def test_every_register_resident_width(oracle, ptmi_lib, emb):
+    """hidden = every multiple of 32 up to 320 x embedding {4, 8, 12, 16}: one nif_kernel_v3 instantiation each."""
+    for hidden in range(32, 321, 32):
+        L = nif_assets.synthetic_nif(hidden=hidden, layer_count=3 + (hidden // 32) % 3, embedding_dim=emb, seed=hidden + emb)
+        _check(oracle, ptmi_lib, L, emb)
+
+
+@pytest.mark.parametrize("hidden,emb", [(96, 8), (160, 16), (288, 4), (224, 12)])
+def test_deep_networks_take_the_v2_ring(oracle, ptmi_lib, hidden, emb):
+    """More than 8 dense layers: nif_kernel_v2 (layer 0 and all biases resident)."""
+    L = nif_assets.synthetic_nif(hidden=hidden, layer_count=10, embedding_dim=emb, seed=3 * hidden + emb)
+    _check(oracle, ptmi_lib, L, emb)
+
+
+@pytest.mark.parametrize("widths,emb,skips", [
+    ([100, 60, 200], 10, {2}),        # ragged widths, embedding not a multiple of 4 -> zero-padded to 224 / 12
+    ([320, 17, 320], 12, {1, 3}),     # a bottleneck, two concat layers, the head takes concat(x, input)
+    ([48], 3, set()),                 # layer 0 + head only
+    ([400, 300], 12, {1}),            # wider than 320 -> layer-by-layer path padded to 512
+    ([768, 768, 768], 5, {2}),        # 768 = 3 feature blocks of 256
+])
+def test_arbitrary_dense_stacks(oracle, ptmi_lib, widths, emb, skips):
+    L = nif_assets.synthetic_nif(widths=widths, embedding_dim=emb, skips=skips, seed=99 + len(widths))
+    assert ptmi_lib  # shapes as the reference would see them
+    _check(oracle, ptmi_lib, L, emb, sizes=(1, 65, 2000))
+
+
+def test_bias_free_and_linear_layers(oracle, ptmi_lib):
+    """use_bias=False layers (Hdf5Model.cpp:77-82) and 'linear' hidden activations (NifModel.cpp:73-76)."""
+    L = nif_assets.synthetic_nif(hidden=128, layer_count=4, embedding_dim=8, seed=21)
+    L = [(k, None if i in (1, 4) else b, relu and i != 2) for i, (k, b, relu) in enumerate(L)]
+    _check(oracle, ptmi_lib, L, 8)
+
+
+def test_float32_weights_are_rounded_to_half_on_upload(oracle, ptmi_lib):
+    """A Keras H5 with float32 variables loads (Hdf5Model.cpp:109-133).  The reference would then run float layers;
+    here the kernels are RNE-rounded to binary16 on upload, so the result is bit-identical to uploading the rounded
+    weights, and within the stated tolerance of the oracle evaluated on the rounded weights."""
+    L32 = nif_assets.synthetic_nif(hidden=320, layer_count=6, seed=5, dtype=np.float32)
+    assert L32[0][0].dtype == np.float32
+    L16 = [(k.astype(np.float16), b.astype(np.float16), relu) for k, b, relu in L32]
+    mean = nif_assets.folded_mean()
+    rng = np.random.default_rng(1)
+    u = rng.random(5000, dtype=np.float32)
+    v = rng.random(5000, dtype=np.float32)
+    r = ptmi_lib.Renderer(64, 64)
+    r.init_nif_weights(L32, 12, META["max"], mean)
+    a = r.nif_infer(u, v)
+    r.init_nif_weights(L16, 12, META["max"], mean)
+    b = r.nif_infer(u, v)
+    r.close()
+    assert a.tobytes() == b.tobytes()
+    _check(oracle, ptmi_lib, L32, 12)
+
+
+def test_shapes_the_reference_would_reject(ptmi_lib):
+    r = ptmi_lib.Renderer(32, 32)
+    good = nif_assets.synthetic_nif(hidden=64, layer_count=2)
+    for bad in (
+        good[:-1] + [(np.zeros((64, 4), np.float16), None, False)],            # head is not 3-wide
+        [(np.zeros((40, 64), np.float16), None, True)] + good[1:],             # first layer does not take 4*E features
+        good[:1] + [(np.zeros((70, 64), np.float16), None, True)] + good[2:],  # neither width nor width + 4*E
+        good[:1],                                                              # a single layer
+    ):
+        with pytest.raises(ptmi_lib.PtError) as e:
+            r.init_nif_weights(bad, 12, 1.0, [0, 0, 0])
+        assert e.value.code == -4   # PT_ERR_UNSUPPORTED_MODEL
+    with pytest.raises(ptmi_lib.PtError):
+        r.init_nif_weights(good, 17, 1.0, [0, 0, 0])                            # embedding > 16
+    r.close()
