@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PTMI_ABI_VERSION 1
+#define PTMI_ABI_VERSION 2
 
 typedef struct pt_context* pt_handle;
 
@@ -45,7 +45,8 @@ enum pt_status {
   PT_ERR_HIP = -3,
   PT_ERR_UNSUPPORTED_MODEL = -4,
   PT_ERR_NOT_READY = -5,
-  PT_ERR_OUT_OF_MEMORY = -6
+  PT_ERR_OUT_OF_MEMORY = -6,
+  PT_ERR_COMM = -7
 };
 
 enum { PT_AA_NORMAL = 0, PT_AA_UNIFORM = 1, PT_AA_TRUNCATED_NORMAL = 2 }; /* PathTracerApp.cpp:29-45 */
@@ -142,9 +143,40 @@ int pt_read_results(pt_handle h, pt_trace_record* work, size_t n, pt_stats* stat
 /* Stats of the last path_trace without the device -> host copy. */
 int pt_get_stats(pt_handle h, pt_stats* stats);
 
-/* Multi-GPU film hand-off: write mean radiance per work item, BGR float32 [n][3] (the value
- * AccumulatedImage::accumulate adds, AccumulatedImage.cpp:59-74: (b,g,r)/sampleCount), into a
- * DEVICE buffer on the handle's stream so the caller can gather HDR tiles with RCCL. */
+/* Multi-GPU film hand-off.  The path shards over pixels with no exchange of ray data (reference: one NIF
+ * replica per IPU, "no inter-ipu exchange of ray data", PathTracerApp.cpp:205-252, shard_utils.cpp:28-38);
+ * the only exchange is the film: mean radiance per work item, BGR float32 [n][3] -- the value
+ * AccumulatedImage::accumulate adds, AccumulatedImage.cpp:59-74: (b,g,r)/sampleCount, with the device's
+ * 32-bit sample count (0 samples -> 0).
+ *
+ * pt_export_hdr_device writes this rank's tile into a caller-owned DEVICE buffer on the handle's stream.
+ *
+ * pt_film_accumulate keeps the film on the device between save intervals: it is AccumulatedImage::accumulate
+ * (AccumulatedImage.cpp:59-74: film += (b,g,r) * (1/sampleCount)) followed by
+ * LoadBalancer::clearInactiveAccumulators (LoadBalancer.cpp:198-213) for every work item, with the host's fp32
+ * expressions, so the resident film equals the host film bit for bit.  pt_setup starts a new (zero) film.
+ *
+ * pt_gather_hdr is the whole hand-off as one call, made by every rank of the communicator: take this rank's
+ * tile -- PT_HDR_ACCUMULATORS: mean radiance of the current accumulators (as pt_export_hdr_device);
+ * PT_HDR_FILM: the resident film's running sum (the host divides by the step count when it saves,
+ * AccumulatedImage.cpp:24,54) -- into a slot of `slot_items` items (>= this rank's item count, equal on all
+ * ranks, zero padded), ONE RCCL gather to rank 0 (grouped ncclSend/ncclRecv: every peer sends directly to the
+ * root over its own xGMI link), and on rank 0 a copy of all tiles [world][slot_items][3] into `root_host_bgr`
+ * (ignored on the other ranks; may be NULL).  Blocking.  Without a communicator it degenerates to export +
+ * copy of one tile.
+ *
+ * Communicators: one rank per handle.  One process per GPU: rank 0 calls pt_comm_get_unique_id, hands the
+ * PT_COMM_ID_BYTES bytes to the other processes by any means (MPI, torch.distributed, a file), everyone calls
+ * pt_comm_init_rank.  One process driving several GPUs (ipu_trace --ipus N): pt_comm_init_all on the list of
+ * handles; pt_gather_hdr is then called from one thread per handle.  pt_destroy releases the communicator. */
+enum { PT_HDR_ACCUMULATORS = 0, PT_HDR_FILM = 1 };
+#define PT_COMM_ID_BYTES 128
+int pt_comm_get_unique_id(void* id_out);
+int pt_comm_init_rank(pt_handle h, const void* id, int rank, int world);
+int pt_comm_init_all(pt_handle* handles, int n);
+int pt_comm_info(pt_handle h, int* rank, int* world);
+int pt_film_accumulate(pt_handle h);
+int pt_gather_hdr(pt_handle h, int32_t source, size_t slot_items, float* root_host_bgr);
 int pt_export_hdr_device(pt_handle h, void* device_bgr, size_t n);
 /* Clear r,g,b,sampleCount,pathLength on the device worklist
  * (LoadBalancer::clearInactiveAccumulators, LoadBalancer.cpp:198-213) without a host round trip. */

@@ -29,7 +29,9 @@ def build_library(force=False, verbose=False):
     if not force and _newer(out, srcs):
         return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + HIPCC_FLAGS + ["-I" + os.path.join(_ROOT, "include"), "-o", out, os.path.join(_CSRC, "ptmi.hip")]
+    # librccl is linked directly: the HDR-tile gather (pt_gather_hdr) is part of the product boundary
+    cmd = [hipcc] + HIPCC_FLAGS + ["-I" + os.path.join(_ROOT, "include"), "-o", out, os.path.join(_CSRC, "ptmi.hip"),
+                                   "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

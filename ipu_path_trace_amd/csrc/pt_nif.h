@@ -877,16 +877,35 @@ __global__ void accumulate_kernel(uint32_t n, uint32_t iters, const uint8_t* ple
 }
 
 // (b, g, r) / sampleCount per work item: the value AccumulatedImage::accumulate adds
-// (src/AccumulatedImage.cpp:69-71), for the multi-GPU HDR gather.
+// (src/AccumulatedImage.cpp:69-71), for the multi-GPU HDR gather.  The device keeps sampleCount in 32 bits, so a film
+// that stays resident over many steps (count > 65535) still divides by the true count; only the TraceRecord wire
+// format wraps at 16 bits (pack_records_kernel).
 __global__ void export_hdr_kernel(uint32_t n, Accum A, float* bgr) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   // an item that has no samples yet (after pt_setup / pt_clear_accumulators) exports 0, not 0/0
-  const uint32_t cnt = (uint16_t)A.count[i];
+  const uint32_t cnt = A.count[i];
   const float scale = cnt ? 1.f / (float)cnt : 0.f;
   bgr[3 * (size_t)i + 0] = A.b[i] * scale;
   bgr[3 * (size_t)i + 1] = A.g[i] * scale;
   bgr[3 * (size_t)i + 2] = A.r[i] * scale;
+}
+
+// Resident film: AccumulatedImage::accumulate (src/AccumulatedImage.cpp:59-74: hdr += (b, g, r) * (1 / sampleCount))
+// followed by LoadBalancer::clearInactiveAccumulators (src/LoadBalancer.cpp:198-213) for one work item, on the device.
+// Same fp32 expressions as the host code (no contraction), so a film kept here equals the host film bit for bit.
+__global__ void film_accumulate_kernel(uint32_t n, Accum A, float* film) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t cnt = (uint16_t)A.count[i];     // the host divides by the uint16 wire field
+  if (cnt) {
+    const float scale = 1.f / (float)cnt;
+    film[3 * (size_t)i + 0] += A.b[i] * scale;
+    film[3 * (size_t)i + 1] += A.g[i] * scale;
+    film[3 * (size_t)i + 2] += A.r[i] * scale;
+  }
+  A.r[i] = 0.f; A.g[i] = 0.f; A.b[i] = 0.f;
+  A.count[i] = 0; A.length[i] = 0;
 }
 
 }  // namespace ptd

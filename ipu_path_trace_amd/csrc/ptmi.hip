@@ -3,6 +3,7 @@
 // Build (see __graft_entry__.build): hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC
 // -ffp-contract=off is part of the numerical contract (pt_device_math.h).
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <atomic>
@@ -129,6 +130,16 @@ struct pt_context {
   // scratch for the standalone entry points
   void* d_scratch = nullptr;
   size_t scratch_bytes = 0;
+
+  // multi-GPU film hand-off: RCCL communicator (one rank per handle) and the HDR tile buffers
+  ncclComm_t comm = nullptr;
+  int comm_rank = 0, comm_world = 1;
+  float* d_film = nullptr;         // resident film: [capacity][3] BGR, sum over steps of the per-step means
+  uint32_t film_steps = 0;
+  float* d_hdr_stage = nullptr;    // this rank's tile: [slot_items][3] mean BGR, zero padded
+  size_t hdr_stage_floats = 0;
+  float* d_hdr_gather = nullptr;   // root only: [world][slot_items][3]
+  size_t hdr_gather_floats = 0;
 };
 
 namespace {
@@ -797,6 +808,8 @@ int pt_destroy(pt_handle h) {
   (void)hipFree(h->d_wpack); (void)hipFree(h->d_bpack);
   (void)hipFree(h->d_gemm_act[0]); (void)hipFree(h->d_gemm_act[1]); (void)hipFree(h->d_gemm_feat); (void)hipFree(h->d_tile_start);
   (void)hipFree(h->d_scratch);
+  (void)hipFree(h->d_hdr_stage); (void)hipFree(h->d_hdr_gather); (void)hipFree(h->d_film);
+  if (h->comm) (void)ncclCommDestroy(h->comm);
   for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
   if (h->trace_stream && !h->serial) { (void)hipStreamSynchronize(h->trace_stream); (void)hipStreamDestroy(h->trace_stream); }
   if (h->acc_stream) { (void)hipStreamSynchronize(h->acc_stream); (void)hipStreamDestroy(h->acc_stream); }
@@ -931,6 +944,8 @@ int pt_setup(pt_handle h, const pt_trace_record* work, size_t n) {
   if (n > h->capacity) return fail(h, PT_ERR_INVALID_ARGUMENT, "worklist larger than max_work_items");
   PT_HIP(hipSetDevice(h->cfg.device));
   h->n_items = (uint32_t)n;
+  h->film_steps = 0;
+  if (h->d_film) PT_HIP(hipMemsetAsync(h->d_film, 0, (size_t)h->capacity * 12, h->stream));   // a new worklist starts a new film
   if (n == 0) return PT_OK;
   static_assert(sizeof(pt_trace_record) == 20 && sizeof(ptd::TraceRecordDev) == 20, "TraceRecord wire format");
   PT_HIP(hipMemcpyAsync(h->d_records, work, n * sizeof(pt_trace_record), hipMemcpyHostToDevice, h->stream));
@@ -1171,6 +1186,141 @@ int pt_trace_paths(pt_handle h, const uint16_t* u, const uint16_t* v, const uint
   PT_HIP(hipGetLastError());
   PT_HIP(hipMemcpyAsync(out, d_out, n * sizeof(pt_path_record), hipMemcpyDeviceToHost, h->stream));
   PT_HIP(hipStreamSynchronize(h->stream));
+  return PT_OK;
+}
+
+// ---- multi-GPU film hand-off over RCCL --------------------------------------------------------------------------
+// The path shards over pixels with no exchange of ray data (reference: one NIF replica per IPU, "no inter-ipu exchange",
+// PathTracerApp.cpp:205-252; results only meet on the host film, AccumulatedImage.cpp:59-74).  The one exchange step is
+// this gather of HDR tiles to rank 0 at a save interval: every peer sends its tile straight to the root over its own
+// xGMI link (grouped ncclSend / ncclRecv -- never a ring), 12 B per work item.
+
+#define PT_NCCL(call)                                                                        \
+  do {                                                                                       \
+    ncclResult_t r_ = (call);                                                                \
+    if (r_ != ncclSuccess) {                                                                 \
+      h->error = std::string(#call) + ": " + ncclGetErrorString(r_);                         \
+      return PT_ERR_COMM;                                                                    \
+    }                                                                                        \
+  } while (0)
+
+int pt_comm_get_unique_id(void* id_out) {
+  static_assert(sizeof(ncclUniqueId) == PT_COMM_ID_BYTES, "PT_COMM_ID_BYTES must match ncclUniqueId");
+  if (!id_out) { g_create_error = "null id buffer"; return PT_ERR_INVALID_ARGUMENT; }
+  ncclUniqueId id;
+  ncclResult_t r = ncclGetUniqueId(&id);
+  if (r != ncclSuccess) { g_create_error = std::string("ncclGetUniqueId: ") + ncclGetErrorString(r); return PT_ERR_COMM; }
+  memcpy(id_out, &id, sizeof(id));
+  return PT_OK;
+}
+
+int pt_comm_init_rank(pt_handle h, const void* id_in, int rank, int world) {
+  if (!h) return PT_ERR_INVALID_ARGUMENT;
+  if (!id_in || world < 1 || rank < 0 || rank >= world) return fail(h, PT_ERR_INVALID_ARGUMENT, "bad communicator arguments");
+  if (h->comm) return fail(h, PT_ERR_INVALID_ARGUMENT, "the handle already has a communicator");
+  PT_HIP(hipSetDevice(h->cfg.device));
+  ncclUniqueId id;
+  memcpy(&id, id_in, sizeof(id));
+  PT_NCCL(ncclCommInitRank(&h->comm, world, id, rank));
+  h->comm_rank = rank;
+  h->comm_world = world;
+  return PT_OK;
+}
+
+int pt_comm_init_all(pt_handle* handles, int n) {
+  if (!handles || n < 1) { g_create_error = "bad communicator arguments"; return PT_ERR_INVALID_ARGUMENT; }
+  pt_handle h = handles[0];
+  if (!h) { g_create_error = "null handle"; return PT_ERR_INVALID_ARGUMENT; }
+  std::vector<int> devs(n);
+  for (int i = 0; i < n; ++i) {
+    if (!handles[i]) return fail(h, PT_ERR_INVALID_ARGUMENT, "null handle in the list");
+    if (handles[i]->comm) return fail(h, PT_ERR_INVALID_ARGUMENT, "a handle already has a communicator");
+    devs[i] = handles[i]->cfg.device;
+    for (int j = 0; j < i; ++j)
+      if (devs[j] == devs[i]) return fail(h, PT_ERR_INVALID_ARGUMENT, "RCCL needs one device per rank: two handles share device " + std::to_string(devs[i]));
+  }
+  std::vector<ncclComm_t> comms(n, nullptr);
+  PT_NCCL(ncclCommInitAll(comms.data(), n, devs.data()));
+  for (int i = 0; i < n; ++i) {
+    handles[i]->comm = comms[i];
+    handles[i]->comm_rank = i;
+    handles[i]->comm_world = n;
+  }
+  return PT_OK;
+}
+
+int pt_film_accumulate(pt_handle h) {
+  if (!h) return PT_ERR_INVALID_ARGUMENT;
+  PT_HIP(hipSetDevice(h->cfg.device));
+  if (!h->d_film) {
+    PT_HIP(dev_alloc(&h->d_film, (size_t)h->capacity * 3));
+    PT_HIP(hipMemsetAsync(h->d_film, 0, (size_t)h->capacity * 12, h->stream));
+  }
+  if (h->n_items) {
+    hipLaunchKernelGGL(ptd::film_accumulate_kernel, dim3((h->n_items + 255) / 256), dim3(256), 0, h->stream, h->n_items, h->acc, h->d_film);
+    PT_HIP(hipGetLastError());
+  }
+  h->film_steps += 1;
+  return PT_OK;
+}
+
+int pt_gather_hdr(pt_handle h, int32_t source, size_t slot_items, float* root_host_bgr) {
+  if (!h) return PT_ERR_INVALID_ARGUMENT;
+  if (source != PT_HDR_ACCUMULATORS && source != PT_HDR_FILM) return fail(h, PT_ERR_INVALID_ARGUMENT, "unknown HDR source");
+  if (source == PT_HDR_FILM && !h->d_film) return fail(h, PT_ERR_NOT_READY, "no resident film: pt_film_accumulate has not been called");
+  if (slot_items < h->n_items || slot_items == 0) return fail(h, PT_ERR_INVALID_ARGUMENT, "slot_items must be >= the rank's work items (and > 0)");
+  if (slot_items * 3 >= (1ull << 31)) return fail(h, PT_ERR_INVALID_ARGUMENT, "tile too large");
+  PT_HIP(hipSetDevice(h->cfg.device));
+  const size_t floats = slot_items * 3;
+  if (h->hdr_stage_floats < floats) {
+    if (h->d_hdr_stage) PT_HIP(hipFree(h->d_hdr_stage));
+    h->d_hdr_stage = nullptr; h->hdr_stage_floats = 0;
+    PT_HIP(dev_alloc(&h->d_hdr_stage, floats));
+    h->hdr_stage_floats = floats;
+  }
+  const bool root = h->comm_rank == 0;
+  const size_t world = (size_t)h->comm_world;
+  if (root && world > 1 && h->hdr_gather_floats < world * floats) {
+    if (h->d_hdr_gather) PT_HIP(hipFree(h->d_hdr_gather));
+    h->d_hdr_gather = nullptr; h->hdr_gather_floats = 0;
+    PT_HIP(dev_alloc(&h->d_hdr_gather, world * floats));
+    h->hdr_gather_floats = world * floats;
+  }
+  if (h->n_items < slot_items)
+    PT_HIP(hipMemsetAsync(h->d_hdr_stage + 3 * (size_t)h->n_items, 0, (slot_items - h->n_items) * 12, h->stream));
+  if (h->n_items) {
+    if (source == PT_HDR_FILM) {
+      PT_HIP(hipMemcpyAsync(h->d_hdr_stage, h->d_film, (size_t)h->n_items * 12, hipMemcpyDeviceToDevice, h->stream));
+    } else {
+      hipLaunchKernelGGL(ptd::export_hdr_kernel, dim3((h->n_items + 255) / 256), dim3(256), 0, h->stream, h->n_items, h->acc, h->d_hdr_stage);
+      PT_HIP(hipGetLastError());
+    }
+  }
+  const float* result = h->d_hdr_stage;
+  if (h->comm && world > 1) {
+    if (root) {
+      PT_HIP(hipMemcpyAsync(h->d_hdr_gather, h->d_hdr_stage, floats * 4, hipMemcpyDeviceToDevice, h->stream));
+      PT_NCCL(ncclGroupStart());
+      for (size_t r = 1; r < world; ++r) {
+        ncclResult_t e = ncclRecv(h->d_hdr_gather + r * floats, floats, ncclFloat, (int)r, h->comm, h->stream);
+        if (e != ncclSuccess) { (void)ncclGroupEnd(); return fail(h, PT_ERR_COMM, std::string("ncclRecv: ") + ncclGetErrorString(e)); }
+      }
+      PT_NCCL(ncclGroupEnd());
+      result = h->d_hdr_gather;
+    } else {
+      PT_NCCL(ncclSend(h->d_hdr_stage, floats, ncclFloat, 0, h->comm, h->stream));
+    }
+  }
+  if (root && root_host_bgr)
+    PT_HIP(hipMemcpyAsync(root_host_bgr, result, world * floats * 4, hipMemcpyDeviceToHost, h->stream));
+  PT_HIP(hipStreamSynchronize(h->stream));   // host buffer is not touched after return
+  return PT_OK;
+}
+
+int pt_comm_info(pt_handle h, int* rank, int* world) {
+  if (!h) return PT_ERR_INVALID_ARGUMENT;
+  if (rank) *rank = h->comm_rank;
+  if (world) *world = h->comm_world;
   return PT_OK;
 }
 

@@ -3,6 +3,7 @@
 // std::logic_error when a job is still pending, waitForCompletion() joins it, isRunning() reports progress.
 #pragma once
 #include <atomic>
+#include <exception>
 #include <functional>
 #include <stdexcept>
 #include <system_error>
@@ -16,7 +17,9 @@ public:
   AsyncTask() = default;
   AsyncTask(const AsyncTask&) = delete;
   AsyncTask& operator=(const AsyncTask&) = delete;
-  virtual ~AsyncTask() { waitForCompletion(); }
+  virtual ~AsyncTask() {
+    try { waitForCompletion(); } catch (...) {}   // a destructor must not throw; the job's failure was not collected
+  }
 
   void run(std::function<void()>&& f) {
     if (worker.joinable()) {
@@ -27,7 +30,8 @@ public:
     task = std::move(f);
     busy.store(true);
     worker = std::thread([this] {
-      task();
+      // an exception must not escape the thread (std::terminate): keep it and rethrow it to whoever joins
+      try { task(); } catch (...) { failure = std::current_exception(); }
       busy.store(false);
     });
   }
@@ -39,6 +43,11 @@ public:
     } catch (const std::system_error&) {
       pt_log::error_("Thread could not be joined.");
     }
+    if (failure) {
+      std::exception_ptr e = failure;
+      failure = nullptr;
+      std::rethrow_exception(e);
+    }
   }
 
   bool isRunning() const { return busy.load(); }
@@ -47,4 +56,5 @@ private:
   std::function<void()> task;
   std::thread worker;
   std::atomic<bool> busy{false};
+  std::exception_ptr failure;
 };

@@ -35,6 +35,7 @@ File::File(const std::string& fileName) {
     if (std::memcmp(&d[off], kSignature, 8) == 0) { sb = off; break; }
   }
   if (sb == std::string::npos) fail("'" + fileName + "' has no HDF5 signature");
+  need(sb, 24, "the superblock");
   const int version = d[sb + 8];
   if (version > 1) fail("superblock version " + std::to_string(version) + " (written with a newer libver) is not supported");
   sizeOffsets = d[sb + 13];
@@ -154,6 +155,8 @@ std::map<std::string, File::Attribute> File::attributes(std::uint64_t headerAddr
   for (const Message& m : objectMessages(headerAddress)) {
     if (m.type != 0x000C) continue;
     const std::size_t p = m.offset;
+    if (m.size < 8) fail("attribute message is too short");
+    need(p, 8, "an attribute message");
     const int version = d[p];
     if (version < 1 || version > 3) fail("unsupported attribute message version");
     const std::size_t nameSize = u(p + 2, 2), dtSize = u(p + 4, 2), dsSize = u(p + 6, 2);
@@ -163,9 +166,11 @@ std::map<std::string, File::Attribute> File::attributes(std::uint64_t headerAddr
     need(nameAt, nameSize, "an attribute name");
     std::string name(reinterpret_cast<const char*>(&d[nameAt]), strnlen(reinterpret_cast<const char*>(&d[nameAt]), nameSize));
     Attribute a;
+    if (q > m.offset + m.size) fail("attribute message overruns its header message");   // sizes come from the file: check first
+    need(dtAt, dtSize, "an attribute datatype");
+    need(dsAt, dsSize, "an attribute dataspace");
     a.datatype.assign(d.begin() + dtAt, d.begin() + dtAt + dtSize);
     a.dataspace.assign(d.begin() + dsAt, d.begin() + dsAt + dsSize);
-    if (q > m.offset + m.size) fail("attribute message overruns its header message");
     a.data.assign(d.begin() + q, d.begin() + m.offset + m.size);
     out[name] = std::move(a);
   }
@@ -228,6 +233,7 @@ Dataset File::openDataSet(const std::string& path) const {
   for (const Message& m : objectMessages(resolve(path))) {
     const std::size_t p = m.offset;
     if (m.type == 0x0001) {   // dataspace
+      need(p, 8, "a dataspace message");
       const int version = d[p], rank = d[p + 1];
       std::size_t q;
       if (version == 1) q = p + 8;
@@ -236,12 +242,14 @@ Dataset File::openDataSet(const std::string& path) const {
       for (int i = 0; i < rank; ++i) out.shape.push_back((std::size_t)u(q + i * sizeLengths, sizeLengths));
       haveSpace = true;
     } else if (m.type == 0x0003) {   // datatype
+      need(p, 8, "a datatype message");
       const int cls = d[p] & 0x0f;
       out.isFloat = (cls == 1);
       out.elementSize = (std::size_t)u(p + 4, 4);
       if (cls == 1 && (d[p + 1] & 1)) fail("big-endian floating point data is not supported");
       haveType = true;
     } else if (m.type == 0x0008) {   // data layout
+      need(p, 8, "a data layout message");
       const int version = d[p];
       if (version == 3) {
         const int cls = d[p + 1];
@@ -261,7 +269,11 @@ Dataset File::openDataSet(const std::string& path) const {
           const std::uint64_t a = addr(q);
           q += sizeOffsets;
           std::size_t n = 1;
-          for (int i = 0; i < rank; ++i) n *= (std::size_t)u(q + 4 * i, 4);   // last dimension is the element size
+          for (int i = 0; i < rank; ++i) {   // last dimension is the element size
+            const std::size_t dim = (std::size_t)u(q + 4 * i, 4);
+            if (dim && n > d.size() / dim) fail("dataset '" + path + "' is larger than the file");
+            n *= dim;
+          }
           if (a != kUndefined) { need((std::size_t)(base + a), n, "dataset data"); out.bytes.assign(d.begin() + base + a, d.begin() + base + a + n); }
         } else if (cls == 0) {
           q += 4 * rank;
@@ -277,7 +289,10 @@ Dataset File::openDataSet(const std::string& path) const {
   }
   if (!haveSpace || !haveType || !haveLayout) fail("'" + path + "' is not a dataset");
   std::size_t n = out.elementSize;
-  for (auto s : out.shape) n *= s;
+  for (auto s : out.shape) {
+    if (s && n > d.size() / s) fail("dataset '" + path + "' has a shape larger than the file");
+    n *= s;
+  }
   if (out.bytes.size() < n) fail("dataset '" + path + "' holds fewer bytes than its shape needs");
   out.bytes.resize(n);
   return out;

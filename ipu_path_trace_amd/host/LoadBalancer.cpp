@@ -6,6 +6,7 @@
 #include <limits>
 #include <numeric>
 #include <random>
+#include <stdexcept>
 
 #include "logging.hpp"
 
@@ -72,18 +73,23 @@ void LoadBalancer::allocateWorkByPathLength(const IpuJobList& jobs) {
   pt_log::info_("Load balancing started ({} work items)", byLength.size());
   pt_log::info_("Path length min/max: {}/{}", byLength.front().pathLength, byLength.back().pathLength);
 
-  // Deal (shortest, longest) pairs to the jobs in turn until the two ends of the sorted list meet.  Like the
-  // reference this visits every job in each round, so it expects an even item count per job.
+  // Deal (shortest, longest) pairs to the jobs in turn until the two ends of the sorted list meet.  The reference
+  // (LoadBalancer.cpp:160-177) tests `hi > lo` only after a whole round over the jobs, which duplicates and drops items
+  // (and reads out of range) when the item count is not a multiple of 2 x jobs; it never is with the default geometry
+  // (6 workers force an even count per job).  Here the ends are tested before every deal and a single middle item is
+  // dealt once, so the result is a permutation of the input for any count -- identical to the reference's where the
+  // reference's is defined.
   const std::size_t nJobs = jobs.size();
+  if (nJobs == 0) throw std::logic_error("allocateWorkByPathLength needs at least one job.");
   std::vector<RecordList> dealt(nJobs);
   for (RecordList& d : dealt) d.reserve(jobs.front().getPixelCount());
   std::ptrdiff_t lo = 0, hi = static_cast<std::ptrdiff_t>(byLength.size()) - 1;
-  do {
-    for (std::size_t j = 0; j < nJobs; ++j) {
+  while (lo <= hi) {
+    for (std::size_t j = 0; j < nJobs && lo <= hi; ++j) {
       dealt[j].push_back(byLength[static_cast<std::size_t>(lo++)]);
-      dealt[j].push_back(byLength[static_cast<std::size_t>(hi--)]);
+      if (lo <= hi) dealt[j].push_back(byLength[static_cast<std::size_t>(hi--)]);
     }
-  } while (hi > lo);
+  }
   pt_log::info_("Load balancing finished");
 
   std::size_t out = 0;

@@ -1,18 +1,14 @@
 #include "PathTracerApp.hpp"
 
+#include <atomic>
 #include <cmath>
+#include <cstdio>
 #include <fstream>
 #include <stdexcept>
 #include <thread>
 
 #include "AsyncTask.hpp"
 #include "logging.hpp"
-
-const std::string& OptionMap::str(const std::string& k) const {
-  auto it = values.find(k);
-  if (it == values.end()) throw std::runtime_error("the option '--" + k + "' is required but missing");
-  return it->second;
-}
 
 /// Adjust samples per pixel to be a multiple of samples per step (PathTracerApp.cpp:19-27).
 std::size_t roundSamplesPerPixel(std::size_t samplesPerPixel, std::size_t samplesPerIpuStep) {
@@ -81,6 +77,7 @@ std::vector<OptionSpec> PathTracerApp::addToolOptions() {
       // additions of this build
       {"synthetic-nif", 0, "false", false, true, "Use seeded stand-in NIF weights when <assets>/converted.ptnif is absent."},
       {"constant-env", 0, "", false, false, "r,g,b: constant-radiance environment instead of the NIF (BASELINE config C1)."},
+      {"host-film", 0, "false", false, true, "Run the reference's step loop (worklist to the host every step, host film) even without load balancing."},
   };
 }
 
@@ -88,7 +85,11 @@ void PathTracerApp::init(const OptionMap& options) {
   args = options;
   samplesPerPixel = args.u32("samples");
   samplesPerIpuStep = args.u32("samples-per-step");
-  samplesPerPixel = (std::uint32_t)roundSamplesPerPixel(samplesPerPixel, samplesPerIpuStep);
+  if (samplesPerIpuStep) samplesPerPixel = (std::uint32_t)roundSamplesPerPixel(samplesPerPixel, samplesPerIpuStep);
+  // values the reference would divide by (PathTracerApp.cpp:232 `step % saveInterval`, tiles / ipus): reject them up front
+  if (args.u32("ipus") == 0) throw std::runtime_error("--ipus must be at least 1.");
+  if (args.u32("save-interval") == 0) throw std::runtime_error("--save-interval must be at least 1.");
+  if (samplesPerIpuStep == 0) throw std::runtime_error("--samples-per-step must be at least 1.");
   if (args.u32("ui-port") != 0) throw std::runtime_error("The remote user interface is not part of this build (--ui-port must be 0).");
   if (!args.has("constant-env") || args.str("constant-env").empty()) {
     if (!loadNifModels(args.u32("ipus"), args.str("assets"))) throw std::runtime_error("Could not load NIF model.");
@@ -127,17 +128,16 @@ void PathTracerApp::attach() {
   geometry.numTiles *= numDevices;  // tiles scale with the device count as on a multi-IPU target
   const auto raysPerJob = calculateMaxRaysPerTile(imageWidth, imageHeight, geometry);
   ipuJobs.reserve(geometry.numTiles);
-  for (std::size_t t = 0; t < geometry.numTiles; ++t) ipuJobs.emplace_back(raysPerJob, t);
-  const std::size_t itemsPerDevice = raysPerJob * (geometry.numTiles / numDevices);
+  for (std::size_t t = 0; t < geometry.numTiles; ++t) ipuJobs.emplace_back(raysPerJob, args, t);   // PathTracerApp.cpp:323-326
+  const std::size_t jobsPerDevice = geometry.numTiles / numDevices;
+  const std::size_t itemsPerDevice = raysPerJob * jobsPerDevice;
   for (std::size_t d = 0; d < numDevices; ++d) {
     pt_config cfg{};
     cfg.struct_size = sizeof(pt_config);
-    cfg.width = imageWidth;
-    cfg.height = imageHeight;
+    // every job of the device contributes its slice and the per-tile scalars (the host half of buildGraph)
+    for (std::size_t j = 0; j < jobsPerDevice; ++j)
+      ipuJobs[d * jobsPerDevice + j].buildGraph(cfg, d, j * raysPerJob, geometry, args);
     cfg.max_path_length = args.u32("max-path-length");
-    cfg.roulette_depth = args.u32("roulette-depth");
-    cfg.stop_prob = args.f32("stop-prob");
-    cfg.refractive_index = args.f32("refractive-index");
     cfg.aa_noise_type = aaNoiseType(args.str("aa-noise-type"));
     cfg.sample_precision = PT_SAMPLES_HALF;
     cfg.device = (std::int32_t)d;
@@ -145,6 +145,12 @@ void PathTracerApp::attach() {
     pt_handle h = nullptr;
     if (pt_create(&cfg, &h)) throw std::runtime_error(std::string("Could not attach to device: ") + pt_last_error(nullptr));
     devices.push_back(h);
+  }
+  if (numDevices > 1) {
+    // one RCCL communicator over the devices of this process: rank d = device d, HDR tiles are gathered to rank 0
+    if (pt_comm_init_all(devices.data(), (int)numDevices))
+      throw std::runtime_error(std::string("Could not create the RCCL communicator: ") + pt_last_error(devices[0]));
+    pt_log::info_("RCCL communicator over {} devices", numDevices);
   }
   pt_log::info_("Tracebuffer shape: [{}, {}]", ipuJobs.size(), sizeof(TraceRecord) * raysPerJob);
 }
@@ -157,15 +163,25 @@ void PathTracerApp::initialiseState(std::uint32_t imageWidth, std::uint32_t imag
   traceState->work.getWork().active() = traceState->work.getWork().inactive();
 }
 
+template <class F>
+void PathTracerApp::onEveryDevice(const char* what, F&& call) {
+  std::vector<std::string> errors(devices.size());
+  if (devices.size() == 1) {
+    if (call(0)) errors[0] = pt_last_error(devices[0]);
+  } else {
+    std::vector<std::thread> runners;
+    for (std::size_t d = 0; d < devices.size(); ++d)
+      runners.emplace_back([&, d]() { if (call(d)) errors[d] = pt_last_error(devices[d]); });
+    for (auto& t : runners) t.join();
+  }
+  for (auto& e : errors) if (!e.empty()) throw std::runtime_error(std::string(what) + " failed: " + e);
+}
+
 void PathTracerApp::execute() {
   const auto imageWidth = args.u32("width"), imageHeight = args.u32("height");
   const auto seed = args.u64("seed");
   const float antiAliasingScale = args.f32("aa-noise-scale");
   const float fieldOfView = args.f32("fov") * (float)(M_PI / 180.f);      // PathTracerApp.cpp:574
-  const float configExposure = args.f32("exposure"), configGamma = args.f32("gamma");
-  const auto fileName = args.str("outfile");
-  const bool loadBalanceEnabled = args.flag("enable-load-balancing");
-  const auto saveInterval = args.u32("save-interval");
   const auto steps = samplesPerPixel / samplesPerIpuStep;
   const float degrees = args.f32("env-map-rotation");
   const float radians = (degrees / 360.f) * (float)(2.0 * M_PI);          // PathTracerApp.cpp:584
@@ -188,31 +204,102 @@ void PathTracerApp::execute() {
   }
   initialiseState(imageWidth, imageHeight);
 
-  AsyncTask hostProcessing;
   pt_log::info_("Render started");
-  std::size_t totalRays = 0;
+  // The balancer re-deals the worklist from the path lengths every step returns, so it needs the records on the host
+  // each step (the reference's flow).  Without it nothing but the film ever has to leave the devices.
+  if (args.flag("enable-load-balancing") || args.flag("host-film")) executeHostFilm(steps);
+  else executeResidentFilm(steps);
+
+  auto endTime = std::chrono::steady_clock::now();
+  const auto elapsedSecs = std::chrono::duration<double>(endTime - startTime).count();
+  pt_log::info_("Render finished: {} seconds", elapsedSecs);
+  const std::size_t pixelsPerFrame = (std::size_t)imageWidth * imageHeight;
+  finalSamplesPerSec = (pixelsPerFrame / elapsedSecs) * samplesPerPixel;   // PathTracerApp.cpp:786-789
+  pt_log::info_("Samples/sec: {}", finalSamplesPerSec);
+  pt_log::info_("Samples/sec/tile: {}", finalSamplesPerSec / ipuJobs.size());
+}
+
+void PathTracerApp::executeResidentFilm(std::uint32_t steps) {
+  const auto imageWidth = args.u32("width"), imageHeight = args.u32("height");
+  const float configExposure = args.f32("exposure"), configGamma = args.f32("gamma");
+  const auto fileName = args.str("outfile");
+  const auto saveInterval = args.u32("save-interval");
+  AsyncTask hostProcessing;
+
+  // program setup, once: the worklist (pixel coordinates, zero accumulators) goes to the devices and stays there
+  auto& work = traceState->work.getWork().active();
+  const std::size_t itemsPerDevice = work.size() / devices.size();
+  onEveryDevice("setup", [&](std::size_t d) {
+    return pt_setup(devices[d], reinterpret_cast<const pt_trace_record*>(work.data() + d * itemsPerDevice), itemsPerDevice);
+  });
+  std::vector<float> tiles(work.size() * 3);   // rank 0 receives [device][itemsPerDevice][3] BGR film sums
+  RecordList filmRecords;                      // the gathered film as records AccumulatedImage::accumulate takes
+
+  for (auto step = 1u; step <= steps; ++step) {
+    auto loopStartTime = std::chrono::steady_clock::now();
+    std::vector<pt_stats> stats(devices.size());
+    // path_trace, then on the device what the host task does in the reference's loop: film += (b,g,r)/sampleCount and
+    // clear the accumulators (PathTracerApp.cpp:717-745)
+    onEveryDevice("Device step", [&](std::size_t d) {
+      return pt_path_trace(devices[d]) || pt_get_stats(devices[d], &stats[d]) || pt_film_accumulate(devices[d]);
+    });
+    std::size_t totalRays = 0;
+    for (auto& s : stats) totalRays += s.segments;    // what clearInactiveAccumulators sums (LoadBalancer.cpp:198-213)
+    pt_log::debug_("Path-Trace ms: {}", stats[0].path_trace_ms);
+    pt_log::debug_("NIF ms: {}", stats[0].nif_ms);
+    pt_log::debug_("Total ms per step: {}", stats[0].total_ms);
+
+    if (step % saveInterval == 0 || step == steps) {
+      hostProcessing.waitForCompletion();   // the previous save still reads `tiles`
+      // the ONE exchange of the multi-GPU path: HDR tiles to device 0 over RCCL, then to the host film
+      onEveryDevice("HDR gather", [&](std::size_t d) {
+        return pt_gather_hdr(devices[d], PT_HDR_FILM, itemsPerDevice, d == 0 ? tiles.data() : nullptr);
+      });
+      hostProcessing.run([&, step]() {
+        filmRecords = work;
+        for (std::size_t i = 0; i < filmRecords.size(); ++i) {
+          auto& r = filmRecords[i];
+          r.b = tiles[3 * i + 0]; r.g = tiles[3 * i + 1]; r.r = tiles[3 * i + 2];
+          r.sampleCount = 1;                  // accumulate() multiplies by 1 / sampleCount: the sums pass through
+        }
+        traceState->film.reset();
+        traceState->film.accumulate(filmRecords);
+        traceState->film.saveImages(fileName, step, configExposure, configGamma);   // hdr / step, as ever
+        pt_log::info_("Saved images at step {}", step);
+      });
+    }
+
+    auto loopEndTime = std::chrono::steady_clock::now();
+    auto secs = std::chrono::duration<double>(loopEndTime - loopStartTime).count();
+    const auto pixelSamplesPerStep = (double)imageWidth * imageHeight * samplesPerIpuStep;
+    pt_log::info_("Completed render step {}/{} in {} seconds (Samples/sec {}) (Rays/sec {})", step, steps, secs,
+                  pixelSamplesPerStep / secs, totalRays / secs);
+  }
+  hostProcessing.waitForCompletion();
+}
+
+void PathTracerApp::executeHostFilm(std::uint32_t steps) {
+  const auto imageWidth = args.u32("width"), imageHeight = args.u32("height");
+  const float configExposure = args.f32("exposure"), configGamma = args.f32("gamma");
+  const auto fileName = args.str("outfile");
+  const bool loadBalanceEnabled = args.flag("enable-load-balancing");
+  const auto saveInterval = args.u32("save-interval");
+  AsyncTask hostProcessing;
+  std::atomic<std::size_t> totalRays{0};   // written by the host task, read by the step log
   const std::size_t itemsPerDevice = traceState->work.getWork().active().size() / devices.size();
 
   for (auto step = 1u; step <= steps; ++step) {
     auto loopStartTime = std::chrono::steady_clock::now();
 
     // setup -> path_trace -> read_results on every device (PathTracerApp.cpp:692-694).  The worklist is
-    // cut into equal contiguous slices, one per device, as tiles are cut over IPUs; devices run
-    // concurrently and exchange nothing (PathTracerApp.cpp:205-252).
+    // cut into equal contiguous slices, one per device, as tiles are cut over IPUs.
     auto& active = traceState->work.getWork().active();
-    std::vector<std::thread> runners;
-    std::vector<std::string> errors(devices.size());
     std::vector<pt_stats> stats(devices.size());
-    for (std::size_t d = 0; d < devices.size(); ++d) {
-      runners.emplace_back([&, d]() {
-        auto* slice = reinterpret_cast<pt_trace_record*>(active.data() + d * itemsPerDevice);
-        pt_handle h = devices[d];
-        if (pt_setup(h, slice, itemsPerDevice) || pt_path_trace(h) || pt_read_results(h, slice, itemsPerDevice, &stats[d]))
-          errors[d] = pt_last_error(h);
-      });
-    }
-    for (auto& t : runners) t.join();
-    for (auto& e : errors) if (!e.empty()) throw std::runtime_error("Device step failed: " + e);
+    onEveryDevice("Device step", [&](std::size_t d) {
+      auto* slice = reinterpret_cast<pt_trace_record*>(active.data() + d * itemsPerDevice);
+      pt_handle h = devices[d];
+      return pt_setup(h, slice, itemsPerDevice) || pt_path_trace(h) || pt_read_results(h, slice, itemsPerDevice, &stats[d]);
+    });
     pt_log::debug_("Path-Trace ms: {}", stats[0].path_trace_ms);
     pt_log::debug_("NIF ms: {}", stats[0].nif_ms);
     pt_log::debug_("Total ms per step: {}", stats[0].total_ms);
@@ -239,15 +326,7 @@ void PathTracerApp::execute() {
     auto secs = std::chrono::duration<double>(loopEndTime - loopStartTime).count();
     const auto pixelSamplesPerStep = (double)imageWidth * imageHeight * samplesPerIpuStep;
     pt_log::info_("Completed render step {}/{} in {} seconds (Samples/sec {}) (Rays/sec {})", step, steps, secs,
-                  pixelSamplesPerStep / secs, totalRays / secs);
+                  pixelSamplesPerStep / secs, totalRays.load() / secs);
   }
   hostProcessing.waitForCompletion();
-
-  auto endTime = std::chrono::steady_clock::now();
-  const auto elapsedSecs = std::chrono::duration<double>(endTime - startTime).count();
-  pt_log::info_("Render finished: {} seconds", elapsedSecs);
-  const std::size_t pixelsPerFrame = (std::size_t)imageWidth * imageHeight;
-  finalSamplesPerSec = (pixelsPerFrame / elapsedSecs) * samplesPerPixel;   // PathTracerApp.cpp:786-789
-  pt_log::info_("Samples/sec: {}", finalSamplesPerSec);
-  pt_log::info_("Samples/sec/tile: {}", finalSamplesPerSec / ipuJobs.size());
 }

@@ -3,7 +3,6 @@
 #pragma once
 #include <chrono>
 #include <cstdint>
-#include <map>
 #include <memory>
 #include <string>
 #include <vector>
@@ -12,26 +11,8 @@
 #include "IpuPathTraceJob.hpp"
 #include "LoadBalancer.hpp"
 #include "NifModel.hpp"
+#include "Options.hpp"
 #include "ptmi.h"
-
-/// Parsed command line: option name -> value text (the role boost::program_options::variables_map plays).
-struct OptionMap {
-  std::map<std::string, std::string> values;
-  bool has(const std::string& k) const { return values.count(k) != 0; }
-  const std::string& str(const std::string& k) const;
-  std::uint32_t u32(const std::string& k) const { return (std::uint32_t)std::stoul(str(k)); }
-  std::uint64_t u64(const std::string& k) const { return std::stoull(str(k)); }
-  float f32(const std::string& k) const { return std::stof(str(k)); }
-  bool flag(const std::string& k) const { return has(k) && str(k) == "true"; }
-};
-
-struct OptionSpec {
-  std::string name;      // long name
-  char shortName;        // 0 if none
-  std::string defaultValue;
-  bool required, isSwitch;
-  std::string help;
-};
 
 struct PathTracerState {
   PathTracerState(std::uint32_t imageWidth, std::uint32_t imageHeight, std::size_t workItems)
@@ -58,6 +39,15 @@ struct PathTracerApp {
 private:
   bool loadNifModels(std::size_t numDevices, const std::string& assetPath);
   void initialiseState(std::uint32_t imageWidth, std::uint32_t imageHeight);
+  /// One call on every device, each from its own thread (devices run concurrently and exchange no ray data,
+  /// PathTracerApp.cpp:205-252); throws with the first device's message on failure.
+  template <class F> void onEveryDevice(const char* what, F&& call);
+  /// Step loop with the film resident on the devices: path_trace + pt_film_accumulate per step, one RCCL gather of HDR
+  /// tiles to device 0 at every save interval.
+  void executeResidentFilm(std::uint32_t steps);
+  /// Step loop as the reference runs it (setup -> path_trace -> read_results, host film): needed when the balancer
+  /// re-deals the worklist from the returned path lengths every step.
+  void executeHostFilm(std::uint32_t steps);
 
   OptionMap args;
   std::uint32_t samplesPerPixel = 0;

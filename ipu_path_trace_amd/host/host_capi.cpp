@@ -4,6 +4,8 @@
 #include <string>
 
 #include "AccumulatedImage.hpp"
+#include "AsyncTask.hpp"
+#include <stdexcept>
 #include "LoadBalancer.hpp"
 #include "NifModel.hpp"
 #include "PathTracerApp.hpp"
@@ -34,7 +36,8 @@ std::size_t pth_balance_and_clear(TraceRecord* records, std::size_t n, std::size
   lb.getWork().inactive().assign(records, records + n);
   if (balance) {
     IpuJobList jl;
-    for (std::size_t j = 0; j < jobs; ++j) jl.emplace_back(n / jobs, j);
+    OptionMap noArgs;
+    for (std::size_t j = 0; j < jobs; ++j) jl.emplace_back(n / jobs, noArgs, j);
     lb.allocateWorkByPathLength(jl);
   }
   if (balance) std::memcpy(records, lb.getWork().inactive().data(), n * sizeof(TraceRecord));   // balanced order, lengths intact
@@ -78,6 +81,40 @@ int pth_read_metadata(const char* file, double* out8) {
 }
 
 std::size_t pth_round_samples(std::size_t spp, std::size_t per_step) { return roundSamplesPerPixel(spp, per_step); }
+
+// splitTilePixelsOverWorkers (IpuPathTraceJob.cpp:30-52): writes `workers` (start, end) pairs.
+void pth_split_pixels(std::size_t pixels, std::size_t workers, std::size_t* out) {
+  auto v = splitTilePixelsOverWorkers(pixels, workers);
+  for (std::size_t i = 0; i < v.size(); ++i) { out[2 * i] = v[i].first; out[2 * i + 1] = v[i].second; }
+}
+
+// IpuPathTraceJob(maxRayCount, args, core) + buildGraph with the reference's CLI defaults; out = {pixelCount, tile,
+// begin.device, begin.firstRecord, begin.recordCount, end.firstRecord, n worker intervals, cfg.width, cfg.height,
+// cfg.roulette_depth}, fout = {cfg.refractive_index, cfg.stop_prob}.
+int pth_job_build(std::size_t rays, std::size_t core, std::size_t device, std::size_t first, std::size_t* out, float* fout) {
+  try {
+    OptionMap args;
+    for (auto& s : PathTracerApp::addToolOptions()) if (!s.required) args.values[s.name] = s.defaultValue;
+    IpuPathTraceJob job(rays, args, core);
+    pt_config cfg{};
+    DeviceGeometry g;
+    job.buildGraph(cfg, device, first, g, args);
+    out[0] = job.getPixelCount(); out[1] = job.getTile();
+    out[2] = job.beginTraceJob().device; out[3] = job.beginTraceJob().firstRecord; out[4] = job.beginTraceJob().recordCount;
+    out[5] = job.endTraceJob().firstRecord; out[6] = job.workerIntervals().size();
+    out[7] = cfg.width; out[8] = cfg.height; out[9] = cfg.roulette_depth;
+    fout[0] = cfg.refractive_index; fout[1] = cfg.stop_prob;
+    return (int)(IpuPathTraceJob::numChannels * 10 + IpuPathTraceJob::numRayDirComponents);
+  } catch (...) { return -1; }
+}
+
+// AsyncTask: a job that throws must surface at waitForCompletion(), not terminate the process.
+int pth_async_task_rethrows() {
+  AsyncTask t;
+  t.run([] { throw std::runtime_error("boom"); });
+  try { t.waitForCompletion(); } catch (const std::runtime_error& e) { return std::string(e.what()) == "boom" ? 1 : -1; }
+  return 0;
+}
 
 }  // extern "C"
 

@@ -21,7 +21,10 @@ DTYPE_F16, DTYPE_F32 = 0, 1
 
 EXPORTS = ["pt_abi_version", "pt_create", "pt_destroy", "pt_last_error", "pt_upload_nif", "pt_set_constant_env",
            "pt_set_render_settings", "pt_setup", "pt_path_trace", "pt_read_results", "pt_get_stats",
-           "pt_export_hdr_device", "pt_clear_accumulators", "pt_synchronize", "pt_nif_infer", "pt_trace_paths"]
+           "pt_export_hdr_device", "pt_clear_accumulators", "pt_synchronize", "pt_nif_infer", "pt_trace_paths",
+           "pt_comm_get_unique_id", "pt_comm_init_rank", "pt_comm_init_all", "pt_comm_info", "pt_gather_hdr", "pt_film_accumulate"]
+COMM_ID_BYTES = 128
+HDR_ACCUMULATORS, HDR_FILM = 0, 1
 
 
 class PtError(RuntimeError):
@@ -88,6 +91,12 @@ def load_library():
     L.pt_read_results.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(Stats)]
     L.pt_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
     L.pt_export_hdr_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.pt_comm_get_unique_id.argtypes = [C.c_void_p]
+    L.pt_comm_init_rank.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    L.pt_comm_init_all.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+    L.pt_comm_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.pt_gather_hdr.argtypes = [C.c_void_p, C.c_int32, C.c_size_t, C.c_void_p]
+    L.pt_film_accumulate.argtypes = [C.c_void_p]
     L.pt_clear_accumulators.argtypes = [C.c_void_p]
     L.pt_synchronize.argtypes = [C.c_void_p]
     L.pt_nif_infer.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
@@ -198,6 +207,29 @@ class Renderer:
     def export_hdr_device(self, device_ptr, n):
         self._check(self._lib.pt_export_hdr_device(self.handle, C.c_void_p(device_ptr), n))
 
+    # ---- multi-GPU film hand-off (RCCL inside libptmi.so)
+    def comm_init_rank(self, unique_id, rank, world):
+        """Join the RCCL communicator made from `unique_id` (bytes from `comm_unique_id()` on rank 0)."""
+        assert len(unique_id) == COMM_ID_BYTES
+        buf = (C.c_char * COMM_ID_BYTES).from_buffer_copy(unique_id)
+        self._check(self._lib.pt_comm_init_rank(self.handle, buf, rank, world))
+
+    def comm_info(self):
+        rank, world = C.c_int(), C.c_int()
+        self._check(self._lib.pt_comm_info(self.handle, C.byref(rank), C.byref(world)))
+        return rank.value, world.value
+
+    def film_accumulate(self):
+        """AccumulatedImage::accumulate + clearInactiveAccumulators on the device (the film stays resident)."""
+        self._check(self._lib.pt_film_accumulate(self.handle))
+
+    def gather_hdr(self, slot_items, source=HDR_ACCUMULATORS):
+        """One RCCL gather of HDR tiles to rank 0.  Returns float32 [world, slot_items, 3] (BGR) on rank 0, None elsewhere."""
+        rank, world = self.comm_info()
+        out = np.empty((world, slot_items, 3), dtype=np.float32) if rank == 0 else None
+        self._check(self._lib.pt_gather_hdr(self.handle, source, slot_items, out.ctypes.data if out is not None else None))
+        return out
+
     def clear_accumulators(self):
         self._check(self._lib.pt_clear_accumulators(self.handle))
 
@@ -220,6 +252,16 @@ class Renderer:
         self._check(self._lib.pt_trace_paths(self.handle, u.ctypes.data, v.ctypes.data, s.ctypes.data, u.size,
                                              out.ctypes.data))
         return out
+
+
+def comm_unique_id():
+    """ncclGetUniqueId through the C-ABI: rank 0 makes it and hands the bytes to the other ranks."""
+    lib = load_library()
+    buf = (C.c_char * COMM_ID_BYTES)()
+    rc = lib.pt_comm_get_unique_id(buf)
+    if rc:
+        raise PtError(rc, lib.pt_last_error(None).decode())
+    return bytes(buf)
 
 
 def worklist(width, height):

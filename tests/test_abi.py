@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol(ptmi_lib):
     for n in names:
         assert hasattr(lib, n), "libptmi.so does not export %s" % n
     assert sorted(ptmi_lib.EXPORTS) == names
-    assert lib.pt_abi_version() == 1
+    assert lib.pt_abi_version() == 2   # 2: communicator + pt_gather_hdr, PT_DTYPE_F32
 
 
 def test_struct_layouts_match_header(ptmi_lib):
@@ -69,3 +69,17 @@ def test_product_package_never_imports_the_oracle():
                 src = open(os.path.join(d, f), errors="ignore").read()
                 assert "pt_oracle" not in src and "libpt_oracle" not in src, os.path.join(d, f)
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(d, f)
+
+
+def test_comm_entry_points_reject_bad_arguments_without_a_gpu(ptmi_lib):
+    """librccl is linked into libptmi.so (the north_star's RCCL gather lives behind the C-ABI); argument checks need
+    no device."""
+    lib = ptmi_lib.load_library()
+    assert lib.pt_comm_get_unique_id(None) == -1
+    assert lib.pt_comm_init_rank(None, None, 0, 1) == -1
+    assert lib.pt_comm_init_all(None, 0) == -1
+    assert lib.pt_gather_hdr(None, 0, 10, None) == -1
+    assert lib.pt_film_accumulate(None) == -1
+    import subprocess
+    deps = subprocess.run(["readelf", "-d", lib._name], capture_output=True, text=True).stdout
+    assert "librccl.so" in deps

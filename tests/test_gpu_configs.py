@@ -171,3 +171,49 @@ def test_config_c5_wide_nif_8x1024(oracle, ptmi_lib):
     for c in "rgb":
         np.testing.assert_allclose(rec[c], ref[c], rtol=NIF_RTOL, atol=1e-6)
     r.close()
+
+
+def test_redeal_by_measured_path_length_keeps_the_film(ptmi_lib):
+    """SURVEY.md row N3 for the one-process-per-GPU layout, on real data: one interval with the static round-robin deal,
+    tile costs from the path lengths read_results returns, partition.deal_by_path_length, a second interval under the
+    new deal.  Each of the 4 "ranks" is rendered in turn on this GPU.  The film of the second interval equals, bit for
+    bit, the film the static deal would have produced for the same sample indices, and the new deal is better balanced
+    (reference: LoadBalancer::allocateWorkByPathLength, LoadBalancer.cpp:141-192)."""
+    from ipu_path_trace_amd import partition
+    W, H, world, spp = 320, 208, 4, 6
+    L = nif_assets.synthetic_nif(hidden=64, layer_count=2)
+    mean = nif_assets.folded_mean()
+
+    def interval(owner, first_sample_step):
+        """Render `spp` samples (sample indices first_sample_step*spp ...) of every rank's tiles; returns film, costs."""
+        tiles, cost = [], np.zeros(len(owner))
+        for rank in range(world):
+            work = partition.worklist_for_owner(W, H, owner, rank)
+            r = ptmi_lib.Renderer(W, H, max_work_items=partition.max_items_per_rank(W, H, world), max_path_length=8)
+            r.init_nif_weights(L, 12, nif_assets.URBAN_ALLEY_META["max"], mean)
+            r.init_render_settings(samples_per_step=spp)
+            r.setup(work)
+            for _ in range(first_sample_step):            # advance the sample sequence to the interval's first index
+                r.path_trace()
+                r.clear_accumulators()
+            r.path_trace()
+            tiles.append(r.gather_hdr(partition.max_items_per_rank(W, H, world))[0])
+            r.read_results(work)
+            cost += partition.tile_costs(work, W, H)
+            r.close()
+        return partition.assemble_hdr(W, H, world, tiles, owner=owner), cost
+
+    static = partition.round_robin_owner(W, H, world)
+    _, cost = interval(static, 0)
+    dealt = partition.deal_by_path_length(cost, world)
+    assert not np.array_equal(dealt, static)
+    film_static, cost2 = interval(static, 1)
+    film_dealt, cost2b = interval(dealt, 1)
+    assert film_static.tobytes() == film_dealt.tobytes()
+    np.testing.assert_array_equal(cost2, cost2b)          # path lengths are a property of (pixel, sample), not of the deal
+
+    def imbalance(owner):
+        per_rank = np.bincount(owner, weights=cost2, minlength=world)
+        return per_rank.max() / per_rank.mean()
+    assert imbalance(dealt) <= imbalance(static) + 1e-9
+    assert np.bincount(dealt, minlength=world).max() - np.bincount(dealt, minlength=world).min() <= 1

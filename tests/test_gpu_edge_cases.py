@@ -144,3 +144,46 @@ def test_two_handles_and_seed_semantics(ptmi_lib):
     assert again.tobytes() == recs[0].tobytes()
     for r in rs:
         r.close()
+
+
+def test_rccl_gather_of_hdr_tiles_single_rank(ptmi_lib):
+    """pt_gather_hdr at N = 1 on a real RCCL communicator of one rank (ncclGetUniqueId + ncclCommInitRank inside
+    libptmi.so): the gather degenerates to export + copy, with the slot zero-padded.  N > 1 cannot run on a one-GPU
+    box (RCCL refuses two ranks on one device); the tile placement it feeds is covered by tests/test_partition.py."""
+    W = H = 48
+    r = ptmi_lib.Renderer(W, H, max_path_length=6, max_work_items=W * H + 100)
+    r.set_constant_env((0.25, 0.5, 1.0))
+    r.init_render_settings(samples_per_step=3)
+    rec = ptmi_lib.worklist(W, H)
+    r.setup(rec)
+    r.path_trace()
+    a = r.gather_hdr(W * H + 100)                                   # no communicator yet: same call, one tile
+    r.comm_init_rank(ptmi_lib.comm_unique_id(), 0, 1)
+    assert r.comm_info() == (0, 1)
+    b = r.gather_hdr(W * H + 100)
+    r.read_results(rec)
+    exp = np.stack([rec["b"], rec["g"], rec["r"]], -1) * (np.float32(1.0) / rec["sampleCount"].astype(np.float32))[:, None]
+    assert a.shape == b.shape == (1, W * H + 100, 3)
+    np.testing.assert_array_equal(b[0, : W * H], exp)
+    np.testing.assert_array_equal(a, b)
+    assert not b[0, W * H:].any()                                    # padding of the slot
+    with pytest.raises(ptmi_lib.PtError):
+        r.gather_hdr(10)                                             # slot smaller than the tile
+    with pytest.raises(ptmi_lib.PtError):
+        r.gather_hdr(W * H, source=ptmi_lib.HDR_FILM)                # no resident film yet
+    # resident film: two steps folded on the device == AccumulatedImage::accumulate on the host, bit for bit
+    r.setup(ptmi_lib.worklist(W, H))
+    film = np.zeros((W * H, 3), dtype=np.float32)
+    for _ in range(2):
+        r.path_trace()
+        r.read_results(rec)
+        film += np.stack([rec["b"], rec["g"], rec["r"]], -1) * (np.float32(1.0) / rec["sampleCount"].astype(np.float32))[:, None]
+        r.film_accumulate()
+        r.read_results(rec)
+        assert not rec["sampleCount"].any() and not rec["r"].any() and not rec["pathLength"].any()
+    f = r.gather_hdr(W * H + 100, source=ptmi_lib.HDR_FILM)
+    np.testing.assert_array_equal(f[0, : W * H], film)
+    assert not f[0, W * H:].any()
+    with pytest.raises(ptmi_lib.PtError):
+        r.comm_init_rank(ptmi_lib.comm_unique_id(), 0, 1)            # one communicator per handle
+    r.close()

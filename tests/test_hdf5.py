@@ -114,3 +114,42 @@ def test_cli_renders_from_converted_hdf5(host, oracle, tmp_path):
     oracle.render(cfg, oracle.Nif(layers, 12, nif_assets.URBAN_ALLEY_META["max"], nif_assets.folded_mean()), ref, 0, spp)
     exp = np.stack([ref["b"], ref["g"], ref["r"]], -1).reshape(H, W, 3) / spp
     np.testing.assert_allclose(film, exp, rtol=2e-2, atol=1e-6)
+
+
+def test_truncated_and_corrupted_files_fail_cleanly(tmp_path):
+    """User-supplied assets: every truncation and a few hundred byte-level corruptions of a valid Keras H5 (and of a
+    PTNIF side-car) must end in a clean exception.  The loader is built with AddressSanitizer + UBSan here, so an
+    out-of-bounds read that happens not to crash is caught as well."""
+    exe = str(tmp_path / "h5fuzz")
+    srcs = [os.path.join(HOST, f) for f in ("Hdf5Reader.cpp", "Hdf5Model.cpp", "NifModel.cpp")]
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-I" + HOST, "-I" + os.path.join(ROOT, "include"), "-o", exe,
+                           os.path.join(ROOT, "tests", "h5fuzz_main.cpp")] + srcs + ["-Wl,--unresolved-symbols=ignore-all"])
+    layers = nif_assets.synthetic_nif(hidden=32, layer_count=2, embedding_dim=4)
+    meta = tmp_path / "nif_metadata.txt"
+    nif_assets.write_metadata(str(meta), dict(nif_assets.URBAN_ALLEY_META, embedding_dimension=4, hidden_size=32, layer_count=2))
+    good = tmp_path / "good.hdf5"
+    write_keras_h5(str(good), layers, vlen_config=True)
+    ptn = tmp_path / "good.ptnif"
+    nif_assets.write_ptnif(str(ptn), layers, 4)
+    rng = np.random.default_rng(0)
+    files = [str(good), str(ptn)]
+    for src, ext in ((good, ".hdf5"), (ptn, ".ptnif")):
+        raw = np.fromfile(str(src), dtype=np.uint8)
+        cuts = sorted(set(list(range(0, min(raw.size, 700), 7)) + list(rng.integers(0, raw.size, 60))))
+        for k, n in enumerate(cuts):                                   # truncations
+            p = tmp_path / ("cut%d%s" % (k, ext))
+            raw[:n].tofile(str(p))
+            files.append(str(p))
+        for k in range(150):                                           # corruptions: 1..4 bytes set to hostile values
+            m = raw.copy()
+            for pos in rng.integers(0, min(raw.size, 4096), rng.integers(1, 5)):
+                m[pos] = rng.choice([0, 1, 0x7f, 0x80, 0xff, int(rng.integers(0, 256))])
+            p = tmp_path / ("bad%d%s" % (k, ext))
+            m.tofile(str(p))
+            files.append(str(p))
+    r = subprocess.run([exe, str(meta)] + files, capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0:allocator_may_return_null=1"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    loaded, rejected = [int(x) for x in r.stdout.strip().splitlines()[-1].split()[1::2]]
+    assert loaded >= 2 and rejected > 100 and loaded + rejected == len(files)

@@ -30,6 +30,9 @@ def host():
     L.pth_read_metadata.argtypes = [C.c_char_p, C.c_void_p]
     L.pth_round_samples.restype = st
     L.pth_round_samples.argtypes = [st, st]
+    L.pth_split_pixels.restype = None
+    L.pth_split_pixels.argtypes = [st, st, C.c_void_p]
+    L.pth_job_build.argtypes = [st, st, st, st, C.c_void_p, C.c_void_p]
     return L
 
 
@@ -85,6 +88,40 @@ def test_balance_by_path_length_and_clear(host):
     assert host.pth_balance_and_clear(rec2.ctypes.data, rec2.size, jobs, 0) == total
     assert np.all(rec2["pathLength"] == 0) and np.all(rec2["r"] == 0) and np.all(rec2["sampleCount"] == 0)
     assert np.array_equal(rec2["u"], before["u"])
+
+
+@pytest.mark.parametrize("n,jobs", [(7, 2), (9, 4), (3, 8), (1, 1), (30, 4), (81, 8)])
+def test_balance_is_a_permutation_for_any_item_count(host, n, jobs):
+    """The reference's dealing loop (LoadBalancer.cpp:160-177) duplicates and drops items when the count is not a
+    multiple of 2 x jobs (unreachable with its default geometry); here every input item comes out exactly once."""
+    rng = np.random.default_rng(n)
+    rec = np.zeros(n, dtype=TRACE_DTYPE)
+    rec["u"] = np.arange(n)
+    rec["pathLength"] = rng.integers(1, 50, n)
+    before = rec.copy()
+    total = host.pth_balance_and_clear(rec.ctypes.data, n, jobs, 1)
+    assert total == int(before["pathLength"].sum())
+    assert sorted(rec["u"].tolist()) == list(range(n))
+    assert sorted(rec["pathLength"].tolist()) == sorted(before["pathLength"].tolist())
+
+
+def test_ipu_path_trace_job_interface(host):
+    """IpuPathTraceJob(maxRayCount, args, core), buildGraph, beginTraceJob/endTraceJob, splitTilePixelsOverWorkers
+    (IpuPathTraceJob.hpp:43-54, IpuPathTraceJob.cpp:30-52,95-138)."""
+    out = (C.c_size_t * 12)()
+    host.pth_split_pixels(750, 6, out)
+    assert list(out) == [0, 125, 125, 250, 250, 375, 375, 500, 500, 625, 625, 750]
+    host.pth_split_pixels(10, 4, out)                                   # leftovers go to the first workers
+    assert list(out)[:8] == [0, 3, 3, 6, 6, 8, 8, 10]
+    o = (C.c_size_t * 10)()
+    f = (C.c_float * 2)()
+    assert host.pth_job_build(750, 41, 2, 3000, o, f) == 32             # numChannels 3, numRayDirComponents 2
+    assert list(o) == [750, 41, 2, 3000, 750, 3000, 6, 256, 256, 3]     # CLI defaults: 256 x 256, roulette depth 3
+    assert f[0] == pytest.approx(1.5) and f[1] == pytest.approx(0.3)
+
+
+def test_async_task_surfaces_exceptions(host):
+    assert host.pth_async_task_rethrows() == 1
 
 
 def test_film_accumulate_tonemap_and_exr(host, tmp_path):
@@ -156,6 +193,12 @@ def test_cli_contract_without_gpu(host, tmp_path):
     assert r.returncode != 0 and "unrecognised option" in r.stdout
     r = subprocess.run([exe, "-o", "x.png", "--assets", str(tmp_path)], capture_output=True, text=True)
     assert r.returncode != 0 and "Could not load NIF model" in r.stdout    # PathTracerApp.cpp:69-71
+    # values the step loop would divide by are rejected with a message, not a crash
+    for opt, msg in (("--ipus", "--ipus must be at least 1"), ("--save-interval", "--save-interval must be at least 1"),
+                     ("--samples-per-step", "--samples-per-step must be at least 1")):
+        r = subprocess.run([exe, "-o", "x.png", "--assets", str(tmp_path), "--constant-env", "1,1,1", opt, "0"],
+                           capture_output=True, text=True)
+        assert r.returncode == 1 and msg in r.stdout, (opt, r.returncode, r.stdout[-500:])
 
 
 @pytest.mark.gpu
@@ -185,3 +228,46 @@ def test_ipu_trace_end_to_end_matches_oracle(host, oracle, tmp_path):
     exp = np.stack([ref["b"], ref["g"], ref["r"]], -1).reshape(H, W, 3) / (spp * steps)
     np.testing.assert_allclose(film, exp, rtol=2e-2, atol=1e-6)
     assert os.path.getsize(out) > 1000
+
+
+def _run_cli(host, tmp_path, name, extra, W=96, H=80, spp=4, steps=3):
+    exe = os.path.join(HOST, "ipu_trace")
+    assets = tmp_path / "assets.extra"
+    if not assets.exists():
+        assets.mkdir()
+        nif_assets.write_metadata(str(assets / "nif_metadata.txt"))
+        nif_assets.write_ptnif(str(assets / "converted.ptnif"), nif_assets.synthetic_nif(), 12)
+    out = tmp_path / (name + ".png")
+    r = subprocess.run([exe, "--assets", str(assets), "-w", str(W), "-h", str(H), "-s", str(spp * steps),
+                        "--samples-per-step", str(spp), "--max-path-length", "7", "-o", str(out), "--save-interval", "2"] + extra,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    film = np.zeros((H, W, 3), dtype=np.float32)
+    ww, hh = C.c_size_t(), C.c_size_t()
+    assert host.pth_read_exr(str(tmp_path / (name + ".exr")).encode(), film.ctypes.data, film.size, C.byref(ww), C.byref(hh)) == 0
+    return film, r.stdout
+
+
+@pytest.mark.gpu
+def test_cli_resident_film_host_film_and_load_balancing_give_the_same_film(host, oracle, tmp_path):
+    """SURVEY.md rows A17/A18/N3 on the GPU.  Three step loops over the same render:
+    * default: film resident on the device (pt_film_accumulate), one pt_gather_hdr per save interval;
+    * --host-film: the reference's loop (setup -> path_trace -> read_results every step, host film);
+    * --enable-load-balancing: the reference's loop + LoadBalancer::allocateWorkByPathLength from step 2 on
+      (LoadBalancer.cpp:141-192).
+    The RNG is keyed by pixel and absolute sample index and the film arithmetic is the same fp32 expressions, so all
+    three films are bit-identical, and they match the oracle within the NIF tolerance."""
+    O = oracle
+    W, H, spp, steps = 96, 80, 4, 3
+    resident, log = _run_cli(host, tmp_path, "resident", [])
+    assert "Saved images at step 2" in log and "Saved images at step 3" in log and "Completed render step 3/3" in log
+    hostfilm, _ = _run_cli(host, tmp_path, "hostfilm", ["--host-film"])
+    balanced, log = _run_cli(host, tmp_path, "balanced", ["--enable-load-balancing"])
+    assert "Load balancing finished" in log
+    assert resident.tobytes() == hostfilm.tobytes()
+    assert balanced.tobytes() == hostfilm.tobytes()
+    cfg = O.make_config(width=W, height=H, max_path_length=7, env_mode=O.ENV_NIF)
+    ref = O.worklist(W, H)
+    O.render(cfg, O.Nif(nif_assets.synthetic_nif(), 12, nif_assets.URBAN_ALLEY_META["max"], nif_assets.folded_mean()), ref, 0, spp * steps)
+    exp = np.stack([ref["b"], ref["g"], ref["r"]], -1).reshape(H, W, 3) / (spp * steps)
+    np.testing.assert_allclose(resident, exp, rtol=2e-2, atol=1e-6)
