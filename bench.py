@@ -146,28 +146,54 @@ def main():
     r.init_nif_weights(layers, meta["embedding_dimension"], meta["max"], mean)   # program init_nif_weights
     r.init_render_settings(seed=1, aa_noise_scale=0.3, fov_degrees=90.0, samples_per_step=spp)
     r.setup(work)                                                                 # inputs resident in HBM
-    hdr = torch.empty((max(counts), 3), dtype=torch.float32, device="cuda")
-    gathered = [torch.empty_like(hdr) for _ in range(world)] if (world > 1 and rank == 0) else None
+    slot = max(counts)
+    hdr = torch.empty((slot, 3), dtype=torch.float32, device="cuda")
+    gathered = {"tiles": None, "via": "none (one GPU)"}
+
+    # The HDR-tile gather is part of the product: libptmi.so owns an RCCL communicator (one rank per handle) and
+    # pt_gather_hdr sends every rank's tile straight to rank 0.  The ncclUniqueId travels over torch.distributed, which
+    # the driver's launcher has set up anyway.  Should the communicator fail to come up on some rank, every rank falls
+    # back to torch.distributed's gather of the same device buffers and the bench line says so.
+    product_gather = False
+    if world > 1 and not rehearsal:
+        ok, why = 1, ""
+        try:
+            ids = [ptmi.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            r.comm_init_rank(ids[0], rank, world)
+        except Exception as e:   # noqa: BLE001 -- any failure means "use the fallback", on every rank
+            ok, why = 0, str(e)
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        product_gather = bool(flag.item())
+        gathered["via"] = ("pt_gather_hdr (RCCL inside libptmi.so)" if product_gather
+                           else "torch.distributed gather (pt_comm_init_rank failed: %s)" % (why or "on another rank"))
+    elif world > 1:
+        gathered["via"] = "gloo via host memory (rehearsal)"
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def gather_hdr():
-        """One gather of HDR tiles to rank 0 (RCCL send/recv over xGMI; gloo via host memory when rehearsing)."""
+    def gather_hdr(n_items):
+        """One gather of HDR tiles to rank 0: mean BGR of the current accumulators, [world][slot][3] on rank 0."""
         if world == 1:
             return
+        if product_gather:
+            gathered["tiles"] = r.gather_hdr(slot)                      # export + RCCL gather + copy to the host
+            return
+        r.export_hdr_device(hdr.data_ptr(), n_items)
         if rehearsal:
             torch.cuda.synchronize()
             host = hdr.cpu()
             parts = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
             dist.gather(host, parts, dst=0)
-            if rank == 0:
-                for g, p_ in zip(gathered, parts):
-                    g.copy_(p_)
         else:
-            dist.gather(hdr, gathered, dst=0)
+            parts = [torch.empty_like(hdr) for _ in range(world)] if rank == 0 else None
+            dist.gather(hdr, parts, dst=0)
+        if rank == 0:
+            gathered["tiles"] = np.stack([p_.cpu().numpy() for p_ in parts])
 
     film_sum = np.zeros((H, W, 3), dtype=np.float64) if rank == 0 else None   # sum over intervals of mean x steps
     state = {"owner": owner, "work": work, "steps_in_interval": 0}
@@ -175,10 +201,9 @@ def main():
     def hand_off(last):
         """Save-interval film hand-off (AccumulatedImage::accumulate, AccumulatedImage.cpp:59-74): mean BGR per work
         item -> one gather of HDR tiles to rank 0; optionally re-deal tiles by path length (N3) and start afresh."""
-        r.export_hdr_device(hdr.data_ptr(), state["work"].size)
-        gather_hdr()
+        gather_hdr(state["work"].size)
         if rank == 0 and world > 1 and (args.save_interval > 0):
-            film = partition.assemble_hdr(W, H, world, [g.cpu().numpy() for g in gathered], owner=state["owner"])
+            film = partition.assemble_hdr(W, H, world, gathered["tiles"], owner=state["owner"])
             film_sum[...] += film.astype(np.float64) * state["steps_in_interval"]
         if last or args.save_interval <= 0:
             return
@@ -198,8 +223,7 @@ def main():
     if world > 1 and args.warmup:
         # untimed: the first gather sets up RCCL's point-to-point channels (lazily, on first use); the timed hand-off
         # must measure the transfer, not the connection set-up
-        r.export_hdr_device(hdr.data_ptr(), work.size)
-        gather_hdr()
+        gather_hdr(work.size)
     if args.warmup and args.save_interval > 0:
         r.setup(work)                                                         # intervals count timed steps only
     agg = {"escaped": 0, "segments": 0, "paths": 0, "nif_ms": 0.0, "trace_ms": 0.0, "acc_ms": 0.0, "nif_launches": 0}
@@ -318,7 +342,8 @@ def main():
                 out["config"]["save_interval"] = args.save_interval
                 out["config"]["load_balancing"] = bool(redeal)
             else:
-                film = partition.assemble_hdr(W, H, world, [g.cpu().numpy() for g in gathered])
+                film = partition.assemble_hdr(W, H, world, gathered["tiles"])
+            out["config"]["hdr_gather"] = gathered["via"]
             out["config"]["film_mean"] = float(film.mean())
             out["config"]["film_nonzero_fraction"] = float((film.sum(axis=2) > 0).mean())
         if rehearsal:
