@@ -516,7 +516,7 @@ int launch_nif_v3(pt_handle h, const ptd::NifParams& N, int blocks) {
 // Timing-only ablations of the headline kernel (results are garbage): see nif_kernel_v3's DIAG bits.
 template <int HID, int E>
 bool launch_nif_diag(pt_handle h, const ptd::NifParams& N, int blocks) {
-  static const int diag = getenv("PTMI_NIF_DIAG") ? atoi(getenv("PTMI_NIF_DIAG")) : 0;
+  const int diag = getenv("PTMI_NIF_DIAG") ? atoi(getenv("PTMI_NIF_DIAG")) : 0;   // read per launch: A/B rounds interleave in one process
   if constexpr (HID == 320 && E == 12) {
     switch (diag) {
       case 1: launch_nif_v3<HID, E, 8, 2, 1>(h, N, blocks); return true;
@@ -525,6 +525,7 @@ bool launch_nif_diag(pt_handle h, const ptd::NifParams& N, int blocks) {
       case 4: launch_nif_v3<HID, E, 8, 2, 4>(h, N, blocks); return true;
       case 7: launch_nif_v3<HID, E, 8, 2, 7>(h, N, blocks); return true;
       case 15: launch_nif_v3<HID, E, 8, 2, 15>(h, N, blocks); return true;
+      case 16: launch_nif_v3<HID, E, 8, 2, 16>(h, N, blocks); return true;
       default: break;
     }
   }
@@ -543,7 +544,7 @@ int launch_nif_t(pt_handle h, const ptd::NifParams& N, int blocks) {
     if (h->nif_m16) { launch_nif_v4<HID, E, 8, 2>(h, N, blocks); return PT_OK; }
     if (launch_nif_diag<HID, E>(h, N, blocks)) return PT_OK;
     // A/B switch of the profiling build: 1 = weights straight from L2, 2 = LDS ring with 4 waves x 64 samples
-    static const int variant = getenv("PTMI_NIF_VARIANT") ? atoi(getenv("PTMI_NIF_VARIANT")) : 0;
+    const int variant = getenv("PTMI_NIF_VARIANT") ? atoi(getenv("PTMI_NIF_VARIANT")) : 0;
     if (variant == 1) { hipLaunchKernelGGL((ptd::nif_kernel<HID, E, 2>), dim3(blocks), dim3(256), 0, h->stream, N); return PT_OK; }
     if (variant == 2) return launch_nif_v2<HID, E, 2, 4>(h, N, blocks);
     if (variant == 3) return launch_nif_v2<HID, E, 1, 8>(h, N, blocks);
@@ -553,6 +554,14 @@ int launch_nif_t(pt_handle h, const ptd::NifParams& N, int blocks) {
   return launch_nif_v3<HID, E, 8, TPS>(h, N, blocks);
 }
 
+#ifdef PTMI_HEADLINE_ONLY
+// Development build (seconds to compile): only the headline shape is instantiated.
+template <int E>
+int launch_nif_e(pt_handle h, const ptd::NifParams& N, int blocks) {
+  if constexpr (E == 12) { if (h->nif_hidden == 320) return launch_nif_t<320, 12>(h, N, blocks); }
+  return fail(h, PT_ERR_UNSUPPORTED_MODEL, "PTMI_HEADLINE_ONLY build: only hidden 320 / embedding 12 is instantiated");
+}
+#else
 template <int E>
 int launch_nif_e(pt_handle h, const ptd::NifParams& N, int blocks) {
   switch (h->nif_hidden) {
@@ -570,6 +579,7 @@ int launch_nif_e(pt_handle h, const ptd::NifParams& N, int blocks) {
   }
   return fail(h, PT_ERR_UNSUPPORTED_MODEL, "no register-resident NIF kernel for hidden width " + std::to_string(h->nif_hidden));
 }
+#endif
 
 #ifdef PTMI_DIAG_BUILD
 template <int HID, int E>
@@ -595,15 +605,18 @@ int launch_nif_gemm(pt_handle h, const ptd::NifParams& N) {
   const uint32_t n_layers = N.n_layers, chunk = h->gemm_chunk;
   if (!chunk) return fail(h, PT_ERR_NOT_READY, "wide-NIF buffers are not allocated");
   if (FB == 0 || NT % 8u) return fail(h, PT_ERR_UNSUPPORTED_MODEL, "layer-by-layer NIF path needs a hidden width that is a multiple of 256");
-  static std::atomic<unsigned long long> attr_set{0};
+  static std::atomic<unsigned long long> attr_set{0}, attr_set_pp{0};
   if (int rc = set_dynamic_lds(h, reinterpret_cast<const void*>(&ptd::nifg_layer_kernel<0>), ptd::kGemmLdsBytes, attr_set)) return rc;
+  if (int rc = set_dynamic_lds(h, reinterpret_cast<const void*>(&ptd::nifg_layer_pp_kernel<0>), ptd::kGemmLdsBytes, attr_set_pp)) return rc;
+  bool pingpong = true;
 #ifdef PTMI_DIAG_BUILD
+  if (const char* e = getenv("PTMI_GEMM_PP")) pingpong = atoi(e) != 0;   // A/B switch of the profiling build, read per launch
   for (const void* fn : {reinterpret_cast<const void*>(&ptd::nifg_layer_kernel<1>), reinterpret_cast<const void*>(&ptd::nifg_layer_kernel<2>),
                          reinterpret_cast<const void*>(&ptd::nifg_layer_kernel<3>), reinterpret_cast<const void*>(&ptd::nifg_layer_kernel<4>),
                          reinterpret_cast<const void*>(&ptd::nifg_layer_kernel<7>), reinterpret_cast<const void*>(&ptd::nifg_layer_kernel<8>),
                          reinterpret_cast<const void*>(&ptd::nifg_layer_kernel<16>)})
     PT_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, ptd::kGemmLdsBytes));
-  static const int gdiag = getenv("PTMI_GEMM_DIAG") ? atoi(getenv("PTMI_GEMM_DIAG")) : 0;   // timing-only ablations
+  const int gdiag = getenv("PTMI_GEMM_DIAG") ? atoi(getenv("PTMI_GEMM_DIAG")) : 0;   // timing-only ablations, read per launch
 #endif
   hipLaunchKernelGGL(ptd::nifg_scan_kernel, dim3(1), dim3(256), 0, h->stream, N.region_count, N.n_regions, h->d_tile_start);
   PT_HIP(hipGetLastError());
@@ -639,6 +652,14 @@ int launch_nif_gemm(pt_handle h, const ptd::NifParams& N) {
       G.act_in = h->d_gemm_act[(l + 1u) & 1u];
       G.act_out = h->d_gemm_act[l & 1u];
 #ifdef PTMI_DIAG_BUILD
+      if (pingpong && gdiag) {
+        for (const void* fn : {reinterpret_cast<const void*>(&ptd::nifg_layer_pp_kernel<1>), reinterpret_cast<const void*>(&ptd::nifg_layer_pp_kernel<2>),
+                               reinterpret_cast<const void*>(&ptd::nifg_layer_pp_kernel<3>)})
+          PT_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, ptd::kGemmLdsBytes));
+        if (gdiag == 1) { hipLaunchKernelGGL(ptd::nifg_layer_pp_kernel<1>, dim3(grid), dim3(512), ptd::kGemmLdsBytes, h->stream, G); continue; }
+        if (gdiag == 2) { hipLaunchKernelGGL(ptd::nifg_layer_pp_kernel<2>, dim3(grid), dim3(512), ptd::kGemmLdsBytes, h->stream, G); continue; }
+        if (gdiag == 3) { hipLaunchKernelGGL(ptd::nifg_layer_pp_kernel<3>, dim3(grid), dim3(512), ptd::kGemmLdsBytes, h->stream, G); continue; }
+      }
       if (gdiag == 1) { hipLaunchKernelGGL(ptd::nifg_layer_kernel<1>, dim3(grid), dim3(512), ptd::kGemmLdsBytes, h->stream, G); continue; }
       if (gdiag == 2) { hipLaunchKernelGGL(ptd::nifg_layer_kernel<2>, dim3(grid), dim3(512), ptd::kGemmLdsBytes, h->stream, G); continue; }
       if (gdiag == 3) { hipLaunchKernelGGL(ptd::nifg_layer_kernel<3>, dim3(grid), dim3(512), ptd::kGemmLdsBytes, h->stream, G); continue; }
@@ -647,7 +668,8 @@ int launch_nif_gemm(pt_handle h, const ptd::NifParams& N) {
       if (gdiag == 8) { hipLaunchKernelGGL(ptd::nifg_layer_kernel<8>, dim3(grid), dim3(512), ptd::kGemmLdsBytes, h->stream, G); continue; }
       if (gdiag == 16) { hipLaunchKernelGGL(ptd::nifg_layer_kernel<16>, dim3(grid), dim3(512), ptd::kGemmLdsBytes, h->stream, G); continue; }
 #endif
-      hipLaunchKernelGGL(ptd::nifg_layer_kernel<0>, dim3(grid), dim3(512), ptd::kGemmLdsBytes, h->stream, G);
+      if (pingpong) hipLaunchKernelGGL(ptd::nifg_layer_pp_kernel<0>, dim3(grid), dim3(512), ptd::kGemmLdsBytes, h->stream, G);
+      else hipLaunchKernelGGL(ptd::nifg_layer_kernel<0>, dim3(grid), dim3(512), ptd::kGemmLdsBytes, h->stream, G);
       PT_HIP(hipGetLastError());
     }
     const uint32_t l = n_layers - 1;
