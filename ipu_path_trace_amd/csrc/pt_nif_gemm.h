@@ -50,211 +50,27 @@ __device__ __forceinline__ uint32_t chunk_tile_count(const uint32_t* total_tiles
 
 // One dense layer over a chunk: D[256 features x 256 samples] per workgroup pass, 8 waves of 128 x 64
 // (4 x 2 accumulator tiles of 32 x 32).  Weights and activations arrive by LDS-DMA into a ring of four stages of
-// two k-steps (8 + 8 pieces each); every wave issues exactly four pieces per stage (two paired loads), so one counted s_waitcnt
-// covers the ring (see nif_kernel_v3), and the loader's cursor runs ahead across output blocks, so a block's
-// epilogue stores overlap the next block's first loads.
+// two k-steps (8 + 8 pieces each); wave w loads weight tile w and sample tile w, both k-steps of a tile with one M0
+// set-up, a uniform base address (SGPR pair) + constant per-lane offset and the instruction's immediate offset for
+// the second piece (a tile's k-steps are contiguous in memory and in the slot: [A: tile][k][1 KiB] | [B: tile][k][1 KiB];
+// with an odd k-step count the last stage's second piece is whatever follows in memory -- in bounds, never multiplied).
+// Every wave issues exactly four loads per stage, so one counted s_waitcnt covers the ring, and the loader's cursor runs
+// ahead across output blocks, so a block's epilogue stores overlap the next block's first loads.
 //
 // Block order: workgroup g sits on XCD g % 8; the n_ftiles / 8 feature blocks of one sample block run at the
 // same time on the same XCD, so the sample block's activation pieces are fetched from HBM / Infinity Cache once
 // and hit that XCD's L2 for the other feature blocks; the layer's weights (<= 2 MiB) stay in every L2.
-// DIAG (timing-only builds, results invalid): bit 0 = no loads into the ring, bit 1 = no LDS reads of fragments,
-// bit 2 = no barrier, bit 3 = every load from one L2-hot piece, bit 4 = activation loads from one L2-hot piece.
-// (Tried and dropped: `nt` on the activation stream, -2.5 %; profiles/r01_g_c5_ablation.txt.)
-template <int DIAG>
-__global__ __launch_bounds__(512, 2) void nifg_layer_kernel(const NifGemmParams P) {
-  constexpr int R = kGemmStages;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* bias_lds = smem;
-  char* ring = smem + kGemmBiasBytes;
-  const uint32_t ring_lds = __builtin_amdgcn_readfirstlane(
-      (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring);
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = wave & 1, wn = wave >> 1;
-  const int h = lane >> 5;
-
-  const uint32_t ntiles = chunk_tile_count(P.total_tiles, P.tile0, P.chunk_tiles);
-  const uint32_t nsb = (ntiles + 7u) / 8u;                 // sample blocks of 8 tiles
-  const uint32_t FB = P.n_ftiles / 8u;                     // feature blocks of 8 tiles
-  const uint32_t xcd = blockIdx.x & 7u, cidx = blockIdx.x >> 3, cpx = gridDim.x >> 3;
-  const uint32_t fb = cidx % FB, sbi0 = cidx / FB, spx = cpx / FB;
-  if (xcd + 8u * sbi0 >= nsb) return;                      // nothing for this workgroup (uniform)
-  const uint32_t nks = P.ks_act + P.ks_in;
-  const uint32_t nst = (nks + kGemmKps - 1u) / kGemmKps;
-
-  for (uint32_t i = threadIdx.x; i < P.n_ftiles * 4u; i += 512u)
-    reinterpret_cast<uint4*>(bias_lds)[i] = P.bpack[(size_t)P.bias_base * 4u + i];
-  __syncthreads();
-
-  // ---- loader: stage (pf_it, pf_st) -> ring slot pf_q % R.  Wave w loads weight tile w and sample tile w, both
-  // k-steps of each with one M0 set-up and one uniform base address (SGPR pair) + a constant per-lane offset: a
-  // tile's k-steps are contiguous in memory and in the slot ([A: tile][k][1 KiB] | [B: tile][k][1 KiB]), so the
-  // instruction's immediate offset addresses the second piece on both sides.  (With an odd k-step count the last
-  // stage's second piece is whatever follows in memory -- in bounds, never multiplied.)
-  const uint32_t lane16 = (uint32_t)lane * 16u;
-  uint32_t pf_it = 0, pf_st = 0, pf_q = 0;
-  auto issue_pair = [&](int which) {   // 0: weights, 1: activations
-    const uint32_t s0 = kGemmKps * pf_st;
-    const char* base;
-    if (which == 0) {
-      const uint32_t j = fb * 8u + (uint32_t)wave;
-      base = reinterpret_cast<const char*>(P.wpack) + ((size_t)(P.piece_base + j * nks + s0) << 10);
-    } else {
-      const uint32_t t = (xcd + 8u * (sbi0 + spx * pf_it)) * 8u + (uint32_t)wave;
-      base = (s0 < P.ks_act) ? reinterpret_cast<const char*>(P.act_in) + (((size_t)t * P.act_stride + s0) << 10)
-                             : reinterpret_cast<const char*>(P.feat) + (((size_t)t * P.feat_stride + (s0 - P.ks_act)) << 10);
-    }
-    if constexpr (DIAG & 8) base = reinterpret_cast<const char*>(P.wpack) + ((size_t)wave << 11);                    // every load L2-hot
-    if constexpr (DIAG & 16) { if (which) base = reinterpret_cast<const char*>(P.wpack) + ((size_t)wave << 11); }   // B loads L2-hot
-    const uint32_t dst = ring_lds + (pf_q % R) * kGemmStageBytes + (uint32_t)which * 16384u + ((uint32_t)wave << 11);
-    if constexpr (!(DIAG & 1)) {
-      uint32_t keep;
-      asm volatile(
-          "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-          "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\ts_mov_b32 m0, %0"
-          : "=&s"(keep)
-          : "v"(lane16), "s"(reinterpret_cast<uint64_t>(base)), "s"(dst)
-          : "memory");
-    }
-  };
-  auto stage_issued = [&]() {
-    pf_q += 1;
-    pf_st += 1;
-    if (pf_st == nst) {
-      // past the last block the cursor stays on it: those loads land in slots nobody reads (uniform load count)
-      if (xcd + 8u * (sbi0 + spx * (pf_it + 1u)) < nsb) { pf_it += 1; pf_st = 0; }
-      else pf_st = nst - 1u;
-    }
-  };
-#pragma unroll
-  for (int k = 0; k < R - 1; ++k) {
-    issue_pair(0);
-    issue_pair(1);
-    stage_issued();
-  }
-
-  // Consumer.  A stage's fragments are read one half-stage ahead of their MFMAs, across the barrier: the barrier sits
-  // in the MIDDLE of stage q (between its two k-steps) and certifies that stage q + 1 has landed, so the first
-  // k-step's fragments of stage q + 1 are fetched under the second k-step's MFMAs of stage q, and the second
-  // k-step's fragments under the first k-step's MFMAs.  Neither the barrier skew nor the burst of 8 waves x 6 LDS
-  // reads behind it is then followed by an MFMA that waits for it.
-  uint32_t q = 0;            // consumer stage
-  uint32_t since_store = 2;  // stages since the last epilogue's 16 stores entered the vmcnt queue
-  half8 A0[4], B0[2], A1[4], B1[2];
-  {
-    if (nst < 4u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    asm volatile("s_barrier" ::: "memory");
-    const uint4* slot = reinterpret_cast<const uint4*>(ring) + lane;
-#pragma unroll
-    for (int a = 0; a < 4; ++a) A0[a] = as_half8(slot[(4 * wm + a) * 128]);
-#pragma unroll
-    for (int b = 0; b < 2; ++b) B0[b] = as_half8(slot[1024 + (2 * wn + b) * 128]);
-  }
-  for (uint32_t it = 0;; ++it) {
-    const uint32_t sb = xcd + 8u * (sbi0 + spx * it);
-    if (sb >= nsb) break;
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int a = 0; a < 4; ++a) { acc[a][0] = (f32x16)(0.0f); acc[a][1] = (f32x16)(0.0f); }
-
-    for (uint32_t st = 0; st < nst; ++st) {
-      const uint4* slot = reinterpret_cast<const uint4*>(ring + (q % R) * kGemmStageBytes) + lane;
-      const uint4* next = reinterpret_cast<const uint4*>(ring + ((q + 1u) % R) * kGemmStageBytes) + lane;
-      q += 1;
-      const bool two = kGemmKps * st + 1u < nks;
-      // (with an odd k-step count the last stage's second half holds a copy of the first: read, not multiplied)
-      if constexpr (!(DIAG & 2)) {
-#pragma unroll
-        for (int a = 0; a < 4; ++a) A1[a] = as_half8(slot[(4 * wm + a) * 128 + 64]);
-#pragma unroll
-        for (int b = 0; b < 2; ++b) B1[b] = as_half8(slot[1024 + (2 * wn + b) * 128 + 64]);
-      } else {
-#pragma unroll
-        for (int a = 0; a < 4; ++a) A1[a] = A0[a];
-        B1[0] = B0[1]; B1[1] = B0[0];
-      }
-      asm volatile("" : "+v"(A0[0]), "+v"(A0[1]), "+v"(A0[2]), "+v"(A0[3]), "+v"(B0[0]), "+v"(B0[1])::"memory");
-#pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0[a], B0[0], acc[a][0], 0, 0, 0);
-        acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0[a], B0[1], acc[a][1], 0, 0, 0);
-      }
-      issue_pair(0);
-#pragma unroll
-      for (int a = 2; a < 4; ++a) {
-        acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0[a], B0[0], acc[a][0], 0, 0, 0);
-        acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0[a], B0[1], acc[a][1], 0, 0, 0);
-      }
-      issue_pair(1);
-      stage_issued();
-      // My pieces of stage q + 1 have landed when at most the younger operations are outstanding: two stages of
-      // four loads, plus the previous block's 16 stores while they are younger than the stage awaited.  All of
-      // this stage's fragments are in registers (lgkmcnt(0)), so behind the barrier its slot is free as well.
-      if (nst < 4u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else if (since_store < 2u) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      if constexpr (!(DIAG & 4)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      since_store += 1;
-      if constexpr (!(DIAG & 2)) {
-#pragma unroll
-        for (int a = 0; a < 4; ++a) A0[a] = as_half8(next[(4 * wm + a) * 128]);
-#pragma unroll
-        for (int b = 0; b < 2; ++b) B0[b] = as_half8(next[1024 + (2 * wn + b) * 128]);
-      }
-      if (two) {
-        asm volatile("" : "+v"(A1[0]), "+v"(A1[1]), "+v"(A1[2]), "+v"(A1[3]), "+v"(B1[0]), "+v"(B1[1])::"memory");
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-          acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1[a], B1[0], acc[a][0], 0, 0, 0);
-          acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1[a], B1[1], acc[a][1], 0, 0, 0);
-        }
-      }
-    }
-
-    // ---- epilogue: fp32 -> fp16 (RNE), + bias in fp16, ReLU; 16 whole pieces per wave, always stored (tiles past
-    // the end of the queue land in the buffer's padding), so the store count the waits above assume is exact
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      const uint32_t j = fb * 8u + 4u * wm + a;
-      const uint4* bp = reinterpret_cast<const uint4*>(bias_lds) + ((size_t)j * 2 + h) * 2;
-      const half8 b_lo = as_half8(bp[0]), b_hi = as_half8(bp[1]);
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        half8 l8, h8;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { l8[i] = (_Float16)acc[a][b][i]; h8[i] = (_Float16)acc[a][b][8 + i]; }
-        l8 = l8 + b_lo;
-        h8 = h8 + b_hi;
-        if (P.relu) {
-          const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-          l8 = __builtin_elementwise_max(l8, z);
-          h8 = __builtin_elementwise_max(h8, z);
-        }
-        const uint32_t t = sb * 8u + 2u * wn + b;
-        uint4* out = P.act_out + ((size_t)t * P.act_stride + 2u * j) * 64 + lane;
-        union { half8 hh; uint4 u; } c0, c1;
-        c0.hh = l8;
-        c1.hh = h8;
-        out[0] = c0.u;
-        out[64] = c1.u;
-      }
-    }
-    since_store = 0;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the run-ahead loads before the wave ends
-}
-
-// ---------------------------------------------------------------- the same layer with the two wave groups in ping-pong
 //
-// nifg_layer_kernel above lets every wave interleave its own LDS-DMA issue, fragment reads and MFMAs; the two waves of
-// a SIMD (w and w + 4) then run the same schedule and stall on LDS-DMA issue (100-185 cycles per instruction inside a
-// busy phase) at the same points, which holds the MFMA pipe at 53 % (profiles/r02b_c5_pmc.json).  Here the workgroup's
-// halves alternate ROLES phase by phase, separated by a workgroup barrier (the arrangement of the guide's 256^2 8-phase
-// GEMM, cdna_hip_programming.md section 5): in every phase one wave of each SIMD issues its eight MFMAs of a k-step back to back at
-// raised priority while its partner issues everything else -- one paired LDS-DMA load for the stage three ahead, the
-// counted wait, the six fragment reads for ITS next k-step -- so the matrix pipe always has an issuer.  Fragments are
-// read one phase before they are multiplied (single-buffered: 24 registers instead of 48).
+// Ping-pong.  The round-1 kernel (nifg_layer_v1_kernel in pt_nif_variants.h) let every wave interleave its own LDS-DMA
+// issue, fragment reads and MFMAs; the two waves of a SIMD (w and w + 4) then ran the same schedule and stalled at the
+// same points (MFMA pipe 53 % busy, profiles/r02b_c5_pmc.json).  Here the workgroup's halves alternate ROLES phase by
+// phase, separated by a workgroup barrier (the arrangement of the guide's 256^2 8-phase GEMM, cdna_hip_programming.md
+// section 5): in every phase one wave of each SIMD issues its eight MFMAs of a k-step back to back at raised priority
+// while its partner issues everything else -- one paired LDS-DMA load for the stage three ahead, the counted wait, the
+// six fragment reads for ITS next k-step -- so the matrix pipe always has an issuer.  Fragments are read one phase
+// before they are multiplied (single-buffered: 24 registers instead of 48).  Both halves run the same code; waves 4-7
+// run it one phase late.  +3.7 % end to end at C5 (profiles/r02_c5_ablation.txt, which also records what did NOT help:
+// dedicated loader waves, deferred stores, and that the barriers cost nothing).
 //
 //   global phase                   4S              4S+1            4S+2            4S+3            4S+4
 //   waves 0-3                      MFMA k0(S)      A-pair, wait,   MFMA k1(S)      B-pair, read    MFMA k0(S+1)
@@ -265,9 +81,10 @@ __global__ __launch_bounds__(512, 2) void nifg_layer_kernel(const NifGemmParams 
 // "wait" = my pieces of stage S + 1 have landed (counted vmcnt); the whole of stage S + 1
 // is certified (both halves have waited by the end of phase 4S+2) before its first reader (waves 0-3 in phase 4S+3).
 // The slot of stage S + 3 is that of stage S - 1, whose last readers finished in phase 4S-1.  Same arithmetic, rounding points and store layout
-// as nifg_layer_kernel.  DIAG bits as there (0, 1, 3, 4).
+// as the fused kernels.  DIAG (timing-only builds, results invalid): bit 0 = no loads into the ring, bit 1 = no LDS reads
+// of fragments, bit 2 = no barrier, bit 3 = every load from one L2-hot piece, bit 4 = activation loads from one L2-hot piece.
 template <int DIAG>
-__global__ __launch_bounds__(512, 2) void nifg_layer_pp_kernel(const NifGemmParams P) {
+__global__ __launch_bounds__(512, 2) void nifg_layer_kernel(const NifGemmParams P) {
   constexpr int R = kGemmStages;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* bias_lds = smem;
@@ -293,7 +110,7 @@ __global__ __launch_bounds__(512, 2) void nifg_layer_pp_kernel(const NifGemmPara
     reinterpret_cast<uint4*>(bias_lds)[i] = P.bpack[(size_t)P.bias_base * 4u + i];
   __syncthreads();
 
-  // ---- loader (as nifg_layer_kernel): wave w loads weight tile w and sample tile w of stage (pf_it, pf_st)
+  // ---- loader: wave w loads weight tile w and sample tile w of stage (pf_it, pf_st) -> ring slot pf_q % R
   const uint32_t lane16 = (uint32_t)lane * 16u;
   uint32_t pf_it = 0, pf_st = 0, pf_q = 0;
   auto issue_pair = [&](int which) {   // 0: weights, 1: activations
@@ -345,7 +162,7 @@ __global__ __launch_bounds__(512, 2) void nifg_layer_pp_kernel(const NifGemmPara
     }
   };
   auto phase_end = [&]() __attribute__((always_inline)) {
-    asm volatile("s_barrier" ::: "memory");
+    if constexpr (!(DIAG & 4)) asm volatile("s_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);   // nothing, MFMAs included, moves across a phase boundary
   };
   uint32_t q = 0;            // consumer stage

@@ -605,18 +605,43 @@ int launch_nif_gemm(pt_handle h, const ptd::NifParams& N) {
   const uint32_t n_layers = N.n_layers, chunk = h->gemm_chunk;
   if (!chunk) return fail(h, PT_ERR_NOT_READY, "wide-NIF buffers are not allocated");
   if (FB == 0 || NT % 8u) return fail(h, PT_ERR_UNSUPPORTED_MODEL, "layer-by-layer NIF path needs a hidden width that is a multiple of 256");
-  static std::atomic<unsigned long long> attr_set{0}, attr_set_pp{0};
+  static std::atomic<unsigned long long> attr_set{0};
   if (int rc = set_dynamic_lds(h, reinterpret_cast<const void*>(&ptd::nifg_layer_kernel<0>), ptd::kGemmLdsBytes, attr_set)) return rc;
-  if (int rc = set_dynamic_lds(h, reinterpret_cast<const void*>(&ptd::nifg_layer_pp_kernel<0>), ptd::kGemmLdsBytes, attr_set_pp)) return rc;
-  bool pingpong = true;
 #ifdef PTMI_DIAG_BUILD
-  if (const char* e = getenv("PTMI_GEMM_PP")) pingpong = atoi(e) != 0;   // A/B switch of the profiling build, read per launch
-  for (const void* fn : {reinterpret_cast<const void*>(&ptd::nifg_layer_kernel<1>), reinterpret_cast<const void*>(&ptd::nifg_layer_kernel<2>),
-                         reinterpret_cast<const void*>(&ptd::nifg_layer_kernel<3>), reinterpret_cast<const void*>(&ptd::nifg_layer_kernel<4>),
-                         reinterpret_cast<const void*>(&ptd::nifg_layer_kernel<7>), reinterpret_cast<const void*>(&ptd::nifg_layer_kernel<8>),
-                         reinterpret_cast<const void*>(&ptd::nifg_layer_kernel<16>)})
-    PT_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, ptd::kGemmLdsBytes));
-  const int gdiag = getenv("PTMI_GEMM_DIAG") ? atoi(getenv("PTMI_GEMM_DIAG")) : 0;   // timing-only ablations, read per launch
+  // A/B switches of the profiling build, read per launch: PTMI_GEMM_KERNEL = v1 (round-1 interleaved kernel) | ld (ping-pong
+  // + loader waves); PTMI_GEMM_DIAG = timing-only ablation bits of the selected kernel
+  const char* gk = getenv("PTMI_GEMM_KERNEL");
+  const int variant = !gk ? 0 : (!strcmp(gk, "v1") ? 1 : (!strcmp(gk, "ld") ? 2 : 0));
+  const int gdiag = getenv("PTMI_GEMM_DIAG") ? atoi(getenv("PTMI_GEMM_DIAG")) : 0;
+  auto launch_layer = [&](const ptd::NifGemmParams& G, uint32_t grid) -> int {
+#define PT_LAYER(KERNEL, THREADS)                                                                                         \
+    do {                                                                                                                  \
+      PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                                 ptd::kGemmLdsBytes));                                                                    \
+      hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(THREADS), ptd::kGemmLdsBytes, h->stream, G);                            \
+      return PT_OK;                                                                                                       \
+    } while (0)
+    if (variant == 2) PT_LAYER(ptd::nifg_layer_ld_kernel<0>, 768);
+    if (variant == 1) switch (gdiag) {
+      case 1: PT_LAYER(ptd::nifg_layer_v1_kernel<1>, 512); case 2: PT_LAYER(ptd::nifg_layer_v1_kernel<2>, 512);
+      case 3: PT_LAYER(ptd::nifg_layer_v1_kernel<3>, 512); case 4: PT_LAYER(ptd::nifg_layer_v1_kernel<4>, 512);
+      case 7: PT_LAYER(ptd::nifg_layer_v1_kernel<7>, 512); case 8: PT_LAYER(ptd::nifg_layer_v1_kernel<8>, 512);
+      case 16: PT_LAYER(ptd::nifg_layer_v1_kernel<16>, 512); default: PT_LAYER(ptd::nifg_layer_v1_kernel<0>, 512);
+    }
+    switch (gdiag) {
+      case 1: PT_LAYER(ptd::nifg_layer_kernel<1>, 512); case 2: PT_LAYER(ptd::nifg_layer_kernel<2>, 512);
+      case 3: PT_LAYER(ptd::nifg_layer_kernel<3>, 512); case 4: PT_LAYER(ptd::nifg_layer_kernel<4>, 512);
+      case 8: PT_LAYER(ptd::nifg_layer_kernel<8>, 512); default: break;
+    }
+#undef PT_LAYER
+    hipLaunchKernelGGL(ptd::nifg_layer_kernel<0>, dim3(grid), dim3(512), ptd::kGemmLdsBytes, h->stream, G);
+    return PT_OK;
+  };
+#else
+  auto launch_layer = [&](const ptd::NifGemmParams& G, uint32_t grid) -> int {
+    hipLaunchKernelGGL(ptd::nifg_layer_kernel<0>, dim3(grid), dim3(512), ptd::kGemmLdsBytes, h->stream, G);
+    return PT_OK;
+  };
 #endif
   hipLaunchKernelGGL(ptd::nifg_scan_kernel, dim3(1), dim3(256), 0, h->stream, N.region_count, N.n_regions, h->d_tile_start);
   PT_HIP(hipGetLastError());
@@ -651,25 +676,7 @@ int launch_nif_gemm(pt_handle h, const ptd::NifParams& N) {
       G.n_ftiles = NT;
       G.act_in = h->d_gemm_act[(l + 1u) & 1u];
       G.act_out = h->d_gemm_act[l & 1u];
-#ifdef PTMI_DIAG_BUILD
-      if (pingpong && gdiag) {
-        for (const void* fn : {reinterpret_cast<const void*>(&ptd::nifg_layer_pp_kernel<1>), reinterpret_cast<const void*>(&ptd::nifg_layer_pp_kernel<2>),
-                               reinterpret_cast<const void*>(&ptd::nifg_layer_pp_kernel<3>)})
-          PT_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, ptd::kGemmLdsBytes));
-        if (gdiag == 1) { hipLaunchKernelGGL(ptd::nifg_layer_pp_kernel<1>, dim3(grid), dim3(512), ptd::kGemmLdsBytes, h->stream, G); continue; }
-        if (gdiag == 2) { hipLaunchKernelGGL(ptd::nifg_layer_pp_kernel<2>, dim3(grid), dim3(512), ptd::kGemmLdsBytes, h->stream, G); continue; }
-        if (gdiag == 3) { hipLaunchKernelGGL(ptd::nifg_layer_pp_kernel<3>, dim3(grid), dim3(512), ptd::kGemmLdsBytes, h->stream, G); continue; }
-      }
-      if (gdiag == 1) { hipLaunchKernelGGL(ptd::nifg_layer_kernel<1>, dim3(grid), dim3(512), ptd::kGemmLdsBytes, h->stream, G); continue; }
-      if (gdiag == 2) { hipLaunchKernelGGL(ptd::nifg_layer_kernel<2>, dim3(grid), dim3(512), ptd::kGemmLdsBytes, h->stream, G); continue; }
-      if (gdiag == 3) { hipLaunchKernelGGL(ptd::nifg_layer_kernel<3>, dim3(grid), dim3(512), ptd::kGemmLdsBytes, h->stream, G); continue; }
-      if (gdiag == 4) { hipLaunchKernelGGL(ptd::nifg_layer_kernel<4>, dim3(grid), dim3(512), ptd::kGemmLdsBytes, h->stream, G); continue; }
-      if (gdiag == 7) { hipLaunchKernelGGL(ptd::nifg_layer_kernel<7>, dim3(grid), dim3(512), ptd::kGemmLdsBytes, h->stream, G); continue; }
-      if (gdiag == 8) { hipLaunchKernelGGL(ptd::nifg_layer_kernel<8>, dim3(grid), dim3(512), ptd::kGemmLdsBytes, h->stream, G); continue; }
-      if (gdiag == 16) { hipLaunchKernelGGL(ptd::nifg_layer_kernel<16>, dim3(grid), dim3(512), ptd::kGemmLdsBytes, h->stream, G); continue; }
-#endif
-      if (pingpong) hipLaunchKernelGGL(ptd::nifg_layer_pp_kernel<0>, dim3(grid), dim3(512), ptd::kGemmLdsBytes, h->stream, G);
-      else hipLaunchKernelGGL(ptd::nifg_layer_kernel<0>, dim3(grid), dim3(512), ptd::kGemmLdsBytes, h->stream, G);
+      if (int rc = launch_layer(G, grid)) return rc;
       PT_HIP(hipGetLastError());
     }
     const uint32_t l = n_layers - 1;
