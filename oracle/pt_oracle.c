@@ -565,6 +565,22 @@ int orc_trace_path(const orc_config* cfg, uint16_t u, uint16_t v, uint32_t sampl
   return 0;
 }
 
+/* Object index (0..5, -1 = environment) seen by the central ray of every pixel: the silhouettes Scene::intersect
+ * (codelets.cpp:183) and pixelToRay (:73) imply together.  Used to pin the INFERRED camera model and scene geometry
+ * against the reference's one rendered image (tests/test_oracle_example_image.py). */
+void orc_object_ids(uint32_t w, uint32_t h, float fov, int8_t* ids) {
+#pragma omp parallel for schedule(static)
+  for (long long r = 0; r < (long long)h; ++r) {
+    for (uint32_t c = 0; c < w; ++c) {
+      float d[3], o[3] = {0.f, 0.f, 0.f}, t, hp[3], n[3];
+      orc_pixel_to_ray((float)c, (float)r, w, h, fov, d);
+      float len = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+      d[0] /= len; d[1] /= len; d[2] /= len;
+      ids[(size_t)r * w + c] = (int8_t)orc_scene_intersect(o, d, &t, hp, n);
+    }
+  }
+}
+
 /* ------------------------------------------------------------------ NIF */
 struct orc_nif {
   uint32_t n_layers;

@@ -126,6 +126,8 @@ int orc_roulette(float u, float stop_prob, float* factor);
 void orc_dir_to_uv(const float d[3], float azimuth, float uv[2]);
 void orc_aa_noise(const orc_config*, uint16_t u, uint16_t v, uint32_t sample_index, float noise[2]);
 void orc_scene_object(int index, float centre[3], float* radius, float colour[3], int32_t* type);
+/* object index per pixel (central ray), -1 = environment */
+void orc_object_ids(uint32_t w, uint32_t h, float fov, int8_t* ids);
 
 #ifdef __cplusplus
 }

@@ -109,6 +109,7 @@ def lib():
         L.orc_dir_to_uv.argtypes = [C.c_void_p, C.c_float, C.c_void_p]
         L.orc_aa_noise.argtypes = [C.POINTER(Config), C.c_uint16, C.c_uint16, C.c_uint32, C.c_void_p]
         L.orc_scene_object.argtypes = [C.c_int, C.c_void_p, fp, C.c_void_p, C.POINTER(C.c_int32)]
+        L.orc_object_ids.argtypes = [C.c_uint32, C.c_uint32, C.c_float, C.c_void_p]
         _lib = L
     return _lib
 
@@ -200,6 +201,13 @@ def render(cfg, nif, records, sample_base, n_samples):
     if rc:
         raise RuntimeError("orc_render failed: %d" % rc)
     return st
+
+
+def object_ids(width, height, fov_radians):
+    """int8 [height, width]: index of the object the central ray of each pixel hits (-1 = environment)."""
+    out = np.empty((height, width), dtype=np.int8)
+    lib().orc_object_ids(width, height, float(fov_radians), out.ctypes.data)
+    return out
 
 
 def philox(ctr, key):

@@ -174,6 +174,33 @@ def test_metadata_parser_matches_reference_fixture(host, tmp_path):
     assert host.pth_read_metadata(str(tmp_path / "missing.txt").encode(), out) == -1
 
 
+REAL_META = os.path.join(ROOT, "tests", "golden", "urban_alley_01_4k_fp16_yuv", "assets.extra", "nif_metadata.txt")
+
+
+def test_reference_metadata_file_parses_identically_in_cpp_and_python(host):
+    """The reference's own nif_metadata.txt (a data fixture, see its README): both parsers against the values written in
+    the file itself, and the hand-copied constants of nif_assets.URBAN_ALLEY_META against the file
+    (NifMetaData.cpp:11-71: fields, the -eps fold into mean :48-53, --layer-size / --layer-count from train_command :56-65)."""
+    doc = json.load(open(REAL_META))
+    assert doc["train_command"].count("--callback-period") == 2 and "embedding_sigma" in doc    # the quirks are in the file
+    out = (C.c_double * 8)()
+    assert host.pth_read_metadata(REAL_META.encode(), out) == 0
+    m = nif_assets.load_metadata(REAL_META)
+    enc = doc["encode_params"]
+    assert (int(out[0]), int(out[1]), int(out[2]), int(out[3])) == (12, 320, 6, 1)
+    assert (m["embedding_dimension"], m["hidden_size"], m["layer_count"], m["log_tone_map"]) == (12, 320, 6, True)
+    assert out[4] == np.float32(enc["max"]) == np.float32(m["max"])
+    folded = [np.float32(np.float32(x) - np.float32(enc["eps"])) for x in enc["mean"]]
+    assert [np.float32(x) for x in out[5:8]] == folded == [np.float32(x) for x in m["mean_folded"]]
+    assert m["original_image_shape"] == [2048, 4096, 3] and m["name"].endswith("urban_alley_01_4k.exr")
+    # the constants the benchmark and the tests use are these, not a re-typed approximation
+    U = nif_assets.URBAN_ALLEY_META
+    assert (U["embedding_dimension"], U["hidden_size"], U["layer_count"]) == (12, 320, 6)
+    assert U["max"] == enc["max"] and U["mean"] == enc["mean"] and U["eps"] == enc["eps"]
+    assert U["log_tone_map"] == enc["log_tone_map"] and U["original_image_shape"] == doc["original_image_shape"]
+    assert nif_assets.folded_mean() == [float(x) for x in folded]
+
+
 def test_cli_contract_without_gpu(host, tmp_path):
     """CLI surface of main.cpp:8-37 + PathTracerApp.cpp:794-830: names, short forms, required options, errors."""
     exe = os.path.join(HOST, "ipu_trace")
