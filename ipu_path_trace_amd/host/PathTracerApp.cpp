@@ -55,7 +55,7 @@ std::vector<OptionSpec> PathTracerApp::addToolOptions() {
       {"height", 'h', "256", false, false, "Output image height (total pixels)."},
       {"samples", 's', "512", false, false, "Total samples to take per pixel."},
       {"samples-per-step", 0, "512", false, false, "Samples to take per device step."},
-      {"interactive-samples", 0, "8", false, false, "Samples per step during user interaction (UI not built)."},
+      {"interactive-samples", 0, "8", false, false, "Number of samples to take per step during user interaction."},
       {"refractive-index", 'n', "1.5", false, false, "Refractive index."},
       {"roulette-depth", 0, "3", false, false, "Number of bounces before rays are randomly stopped."},
       {"stop-prob", 0, "0.3", false, false, "Probability of a ray being stopped."},
@@ -73,7 +73,7 @@ std::vector<OptionSpec> PathTracerApp::addToolOptions() {
       {"partials-type", 0, "half", false, false, "IPU-only: accepted and ignored (MFMA accumulates in fp32)."},
       {"available-memory-proportion", 0, "0.6", false, false, "IPU-only: accepted and ignored."},
       {"max-nif-batch-size", 0, "44160", false, false, "IPU-only: accepted and ignored (the NIF runs on a compacted queue)."},
-      {"ui-port", 0, "0", false, false, "Remote user-interface (not built: must be 0)."},
+      {"ui-port", 0, "0", false, false, "Start a remote user-interface server on the specified port (text protocol, see InterfaceServer.hpp)."},
       // additions of this build
       {"synthetic-nif", 0, "false", false, true, "Use seeded stand-in NIF weights when <assets>/converted.ptnif is absent."},
       {"constant-env", 0, "", false, false, "r,g,b: constant-radiance environment instead of the NIF (BASELINE config C1)."},
@@ -90,7 +90,6 @@ void PathTracerApp::init(const OptionMap& options) {
   if (args.u32("ipus") == 0) throw std::runtime_error("--ipus must be at least 1.");
   if (args.u32("save-interval") == 0) throw std::runtime_error("--save-interval must be at least 1.");
   if (samplesPerIpuStep == 0) throw std::runtime_error("--samples-per-step must be at least 1.");
-  if (args.u32("ui-port") != 0) throw std::runtime_error("The remote user interface is not part of this build (--ui-port must be 0).");
   if (!args.has("constant-env") || args.str("constant-env").empty()) {
     if (!loadNifModels(args.u32("ipus"), args.str("assets"))) throw std::runtime_error("Could not load NIF model.");
   }
@@ -207,7 +206,7 @@ void PathTracerApp::execute() {
   pt_log::info_("Render started");
   // The balancer re-deals the worklist from the path lengths every step returns, so it needs the records on the host
   // each step (the reference's flow).  Without it nothing but the film ever has to leave the devices.
-  if (args.flag("enable-load-balancing") || args.flag("host-film")) executeHostFilm(steps);
+  if (args.flag("enable-load-balancing") || args.flag("host-film") || args.u32("ui-port") != 0) executeHostFilm(steps);
   else executeResidentFilm(steps);
 
   auto endTime = std::chrono::steady_clock::now();
@@ -217,6 +216,39 @@ void PathTracerApp::execute() {
   finalSamplesPerSec = (pixelsPerFrame / elapsedSecs) * samplesPerPixel;   // PathTracerApp.cpp:786-789
   pt_log::info_("Samples/sec: {}", finalSamplesPerSec);
   pt_log::info_("Samples/sec/tile: {}", finalSamplesPerSec / ipuJobs.size());
+}
+
+void PathTracerApp::defunctState(std::uint32_t imageWidth, std::uint32_t imageHeight) {
+  if (defunctTraceState) {
+    defunctTraceState->film.reset();   // avoid reallocation: the worklists are large (PathTracerApp.cpp:512-515)
+  } else {
+    defunctTraceState.reset(new PathTracerState(imageWidth, imageHeight, traceState->work.getWork().active().size()));
+  }
+  // Swap and then copy the up-to-date work from the now defunct worklist:
+  std::swap(traceState, defunctTraceState);
+  traceState->work.getWork().active() = defunctTraceState->work.getWork().active();
+  traceState->work.getWork().inactive() = defunctTraceState->work.getWork().active();
+}
+
+InterfaceServer::Status PathTracerApp::processUserInput(InterfaceServer::State& state, std::uint32_t imageWidth,
+                                                        std::uint32_t imageHeight) {
+  if (state.stop) {
+    pt_log::info_("Rendering stopped by remote UI");
+    return InterfaceServer::Status::Stop;
+  }
+  if (state.detach) {
+    pt_log::info_("Remote UI disconnected.");   // the render just continues
+    return InterfaceServer::Status::Disconnected;
+  }
+  if (!state.newNif.empty()) {
+    pt_log::info_("Loading NIF: {}", state.newNif);
+    if (loadNifModels(models.size(), state.newNif)) {
+      // program init_nif_weights again (PathTracerApp.cpp:548-557): pt_upload_nif is re-callable
+      for (std::size_t d = 0; d < devices.size(); ++d) models[d]->upload(devices[d]);
+    }
+  }
+  defunctState(imageWidth, imageHeight);
+  return InterfaceServer::Status::Restart;
 }
 
 void PathTracerApp::executeResidentFilm(std::uint32_t steps) {
@@ -280,16 +312,61 @@ void PathTracerApp::executeResidentFilm(std::uint32_t steps) {
 
 void PathTracerApp::executeHostFilm(std::uint32_t steps) {
   const auto imageWidth = args.u32("width"), imageHeight = args.u32("height");
-  const float configExposure = args.f32("exposure"), configGamma = args.f32("gamma");
   const auto fileName = args.str("outfile");
   const bool loadBalanceEnabled = args.flag("enable-load-balancing");
   const auto saveInterval = args.u32("save-interval");
+  const auto seed = args.u64("seed");
+  const float antiAliasingScale = args.f32("aa-noise-scale");
   AsyncTask hostProcessing;
   std::atomic<std::size_t> totalRays{0};   // written by the host task, read by the step log
   const std::size_t itemsPerDevice = traceState->work.getWork().active().size() / devices.size();
 
+  // Setup remote user interface (PathTracerApp.cpp:616-633):
+  std::unique_ptr<InterfaceServer> uiServer;
+  InterfaceServer::State state;
+  state.exposure = args.f32("exposure");
+  state.gamma = args.f32("gamma");
+  state.fov = args.f32("fov") * (float)(M_PI / 180.f);
+  state.envRotationDegrees = args.f32("env-map-rotation");
+  state.interactiveSamples = args.u32("interactive-samples");
+  if (const auto uiPort = args.u32("ui-port")) {
+    uiServer.reset(new InterfaceServer((int)uiPort));
+    uiServer->setInitialState(state);
+    uiServer->start();
+    uiServer->initialiseVideoStream(imageWidth, imageHeight);
+  }
+  constexpr std::size_t sampleCountReversionStep = 5;
+  std::uint32_t lastStep = 0;   // steps accumulated into the current film
+  auto sendRenderSettings = [&]() {   // program init_render_settings (PathTracerApp.cpp:678-686)
+    const float radians = (state.envRotationDegrees / 360.f) * (float)(2.0 * M_PI);
+    for (auto h : devices)
+      check(h, pt_set_render_settings(h, seed, antiAliasingScale, state.fov, radians, samplesPerIpuStep), "init_render_settings");
+  };
+
   for (auto step = 1u; step <= steps; ++step) {
     auto loopStartTime = std::chrono::steady_clock::now();
+
+    // Do the simple thing and restart the entire render if any state changed (PathTracerApp.cpp:656-676):
+    if (uiServer && uiServer->stateChanged()) {
+      state = uiServer->consumeState();
+      const auto status = processUserInput(state, imageWidth, imageHeight);
+      if (status == InterfaceServer::Status::Stop) {
+        uiServer.reset();
+        break;
+      }
+      if (status == InterfaceServer::Status::Disconnected) {
+        uiServer.reset();
+      } else if (status == InterfaceServer::Status::Restart) {
+        step = 1;
+        samplesPerIpuStep = state.interactiveSamples;
+      }
+    } else if (uiServer && step == sampleCountReversionStep) {
+      // No UI input for a few steps so revert to performant number of samples:
+      samplesPerIpuStep = args.u32("samples-per-step");
+      pt_log::debug_("Interaction stopped reverting samples per step to: {}", samplesPerIpuStep);
+    }
+    // Render settings can only be updated on these steps (:678-686):
+    if (uiServer && (step == 1 || step == sampleCountReversionStep)) sendRenderSettings();
 
     // setup -> path_trace -> read_results on every device (PathTracerApp.cpp:692-694).  The worklist is
     // cut into equal contiguous slices, one per device, as tiles are cut over IPUs.
@@ -312,13 +389,24 @@ void PathTracerApp::executeHostFilm(std::uint32_t steps) {
     pt_log::debug_("Waited for host film task ms: {}",
                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - deviceDone).count());
 
+    // The work list and film are captured by pointer: user interaction may make them defunct while this runs (:717)
     hostProcessing.run([&, step, workPtr = &traceState->work, filmPtr = &traceState->film]() {
       filmPtr->accumulate(workPtr->getWork().inactive());
+      if (uiServer) {
+        const auto ui = uiServer->getState();
+        uiServer->sendPreviewImage(filmPtr->updateLdrImage(step, ui.exposure, ui.gamma));
+        uiServer->updateProgress((int)step, (int)steps);
+      }
       if (loadBalanceEnabled && step > 1) workPtr->allocateWorkByPathLength(ipuJobs);
       totalRays = workPtr->clearInactiveAccumulators();
       if (step % saveInterval == 0 || step == steps) {
-        filmPtr->saveImages(fileName, step, configExposure, configGamma);
-        pt_log::info_("Saved images at step {}", step);
+        if (uiServer) {
+          // with a UI attached the raw image is transmitted at the save interval instead of saved (:748-753)
+          uiServer->startSendingRawImage(filmPtr->getHdrImage(), step);
+        } else {
+          filmPtr->saveImages(fileName, step, state.exposure, state.gamma);
+          pt_log::info_("Saved images at step {}", step);
+        }
       }
     });
 
@@ -327,6 +415,13 @@ void PathTracerApp::executeHostFilm(std::uint32_t steps) {
     const auto pixelSamplesPerStep = (double)imageWidth * imageHeight * samplesPerIpuStep;
     pt_log::info_("Completed render step {}/{} in {} seconds (Samples/sec {}) (Rays/sec {})", step, steps, secs,
                   pixelSamplesPerStep / secs, totalRays.load() / secs);
+    if (uiServer) uiServer->updateSampleRate((float)(pixelSamplesPerStep / secs), (float)(totalRays.load() / secs));
+    lastStep = step;
   }
   hostProcessing.waitForCompletion();
+  if (args.u32("ui-port") != 0 && lastStep) {
+    // the film the client saw last is also left on disk, so an interactive session ends with an image like a batch run
+    traceState->film.saveImages(fileName, lastStep, state.exposure, state.gamma);
+    pt_log::info_("Saved images at step {}", lastStep);
+  }
 }

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "AccumulatedImage.hpp"
+#include "InterfaceServer.hpp"
 #include "IpuPathTraceJob.hpp"
 #include "LoadBalancer.hpp"
 #include "NifModel.hpp"
@@ -45,6 +46,11 @@ private:
   /// Step loop with the film resident on the devices: path_trace + pt_film_accumulate per step, one RCCL gather of HDR
   /// tiles to device 0 at every save interval.
   void executeResidentFilm(std::uint32_t steps);
+  /// User interaction invalidates all rendering in progress: new (or recycled) tracer state is swapped in and the up-to-date
+  /// worklist copied over, so nobody waits for the defunct host task (PathTracerApp.cpp:507-528).
+  void defunctState(std::uint32_t imageWidth, std::uint32_t imageHeight);
+  /// PathTracerApp.cpp:530-564: stop / detach / NIF hot-reload + restart.
+  InterfaceServer::Status processUserInput(InterfaceServer::State& state, std::uint32_t imageWidth, std::uint32_t imageHeight);
   /// Step loop as the reference runs it (setup -> path_trace -> read_results, host film): needed when the balancer
   /// re-deals the worklist from the returned path lengths every step.
   void executeHostFilm(std::uint32_t steps);
@@ -57,6 +63,7 @@ private:
   std::vector<pt_handle> devices;
   std::vector<std::unique_ptr<NifModel>> models;
   std::unique_ptr<PathTracerState> traceState;
+  std::unique_ptr<PathTracerState> defunctTraceState;   // keeps defunct data alive while the async host task finishes on it
   double finalSamplesPerSec = 0.0;
 };
 

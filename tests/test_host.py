@@ -298,3 +298,92 @@ def test_cli_resident_film_host_film_and_load_balancing_give_the_same_film(host,
     O.render(cfg, O.Nif(nif_assets.synthetic_nif(), 12, nif_assets.URBAN_ALLEY_META["max"], nif_assets.folded_mean()), ref, 0, spp * steps)
     exp = np.stack([ref["b"], ref["g"], ref["r"]], -1).reshape(H, W, 3) / (spp * steps)
     np.testing.assert_allclose(resident, exp, rtol=2e-2, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_interactive_restart_and_nif_hot_reload_over_the_ui_port(host, tmp_path):
+    """SURVEY.md row N4 without the reference's transport (packetcomms / videolib are absent): a text client on
+    --ui-port drives the state machine of PathTracerApp.cpp:507-564,643-686 -- a changed setting restarts the render at
+    step 1 with --interactive-samples per step and a fresh film, settings are re-sent at steps 1 and 5 (where the sample
+    count reverts to --samples-per-step), load_nif hot-swaps the weights through pt_upload_nif, exposure does not restart,
+    stop ends the run."""
+    import socket
+    import threading
+    import time
+    exe = os.path.join(HOST, "ipu_trace")
+    assets = tmp_path / "assets.extra"
+    assets.mkdir()
+    nif_assets.write_metadata(str(assets / "nif_metadata.txt"))
+    nif_assets.write_ptnif(str(assets / "converted.ptnif"), nif_assets.synthetic_nif(), 12)
+    other = tmp_path / "other.extra"
+    other.mkdir()
+    nif_assets.write_metadata(str(other / "nif_metadata.txt"))
+    nif_assets.write_ptnif(str(other / "converted.ptnif"), nif_assets.synthetic_nif(seed=99), 12)
+    W, H = 64, 48
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = tmp_path / "ui.png"
+    proc = subprocess.Popen([exe, "--assets", str(assets), "-w", str(W), "-h", str(H), "-s", "4000", "--samples-per-step", "20",
+                             "--interactive-samples", "2", "--max-path-length", "5", "-o", str(out), "--save-interval", "3",
+                             "--ui-port", str(port), "--log-level", "debug"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    conn = None
+    for _ in range(600):                                   # the server starts listening after the device is attached
+        try:
+            conn = socket.create_connection(("127.0.0.1", port), timeout=1.0)
+            break
+        except OSError:
+            time.sleep(0.1)
+    assert conn is not None, "ui server never came up"
+    got = {"progress": [], "preview": 0, "hdr_rows": 0, "hdr_header": None, "rates": 0}
+
+    def reader():
+        f = conn.makefile("rb")
+        while True:
+            line = f.readline()
+            if not line:
+                return
+            t = line.decode().split()
+            if t[0] == "progress":
+                got["progress"].append(float(t[1]))
+            elif t[0] == "sample_rate":
+                got["rates"] += 1
+            elif t[0] == "render_preview":
+                assert (int(t[1]), int(t[2]), int(t[3])) == (W, H, W * H * 3)
+                assert len(f.read(int(t[3]))) == int(t[3])
+                got["preview"] += 1
+            elif t[0] == "hdr_header":
+                got["hdr_header"] = (int(t[1]), int(t[2]), int(t[3]))
+            elif t[0] == "hdr_packet":
+                assert len(f.read(int(t[2]))) == int(t[2]) == W * 3 * 4
+                got["hdr_rows"] += 1
+
+    th = threading.Thread(target=reader, daemon=True)
+    th.start()
+
+    def wait_for(cond, what, seconds=60):
+        t0 = time.time()
+        while not cond():
+            assert time.time() - t0 < seconds and proc.poll() is None, what
+            time.sleep(0.02)
+
+    wait_for(lambda: len(got["progress"]) >= 7, "no progress from the first render")           # past step 5: reverted to 20 spp
+    conn.sendall(b"exposure 1.5\n")                                                              # host-side only: no restart
+    n = len(got["progress"])
+    wait_for(lambda: len(got["progress"]) >= n + 2, "render stalled after an exposure change")
+    assert got["progress"][-1] > got["progress"][n - 1]                                          # still counting up
+    conn.sendall(b"env_rotation 40\n")                                                           # restart at step 1
+    m = len(got["progress"])
+    wait_for(lambda: any(p < got["progress"][m - 1] for p in got["progress"][m:]), "no restart after env_rotation")
+    conn.sendall(("load_nif %s\n" % other).encode())                                             # hot reload + restart
+    time.sleep(0.5)
+    wait_for(lambda: got["hdr_header"] is not None and got["hdr_rows"] >= H, "no raw film transfer at the save interval")
+    conn.sendall(b"stop\n")
+    log, _ = proc.communicate(timeout=60)
+    assert proc.returncode == 0, log[-3000:]
+    assert "Rendering stopped by remote UI" in log and "Loading NIF: %s" % other in log
+    assert log.count("Completed render step 1/200") >= 3                                         # first run + two restarts
+    assert "Interaction stopped reverting samples per step to: 20" in log
+    assert got["hdr_header"] == (W, H, H) and got["preview"] >= 8 and got["rates"] >= 8
+    assert os.path.getsize(out) > 500                                                            # the last film is left on disk
