@@ -33,6 +33,7 @@ struct NifGemmParams {
   uint32_t act_stride, feat_stride;
   const uint32_t* total_tiles;   // device scalar: 32-sample tiles in the queue
   uint32_t tile0, chunk_tiles;   // this launch covers queue tiles [tile0, tile0 + chunk_tiles)
+  unsigned long long* stamps;    // profiling build only (DIAG bit 6): phase time stamps of workgroup 0, else nullptr
 };
 
 constexpr int kGemmStages = 4;                  // ring slots
@@ -145,50 +146,85 @@ __global__ __launch_bounds__(512, 2) void nifg_layer_kernel(const NifGemmParams 
       else pf_st = nst - 1u;
     }
   };
+  // Phases per stage.  Four (product): MFMA k0 | load | MFMA k1 | load.  Two (DIAG bit 7, valid results): one MFMA phase of
+  // 16 MFMAs and one load phase per stage with the loader four stages ahead -- measured equal (1084 vs 1087 TFLOP/s at C5,
+  // profiles/r02_c5_ablation.txt) at 190 instead of 166 VGPRs, so the shorter phases stay.
+  constexpr bool kTwoPhase = (DIAG & 128) != 0;
+  constexpr int kAhead = kTwoPhase ? R : R - 1;   // stages the loader runs ahead of the stage being multiplied
 #pragma unroll
-  for (int k = 0; k < R - 1; ++k) {
+  for (int k = 0; k < kAhead; ++k) {
     issue_pair(0);
     issue_pair(1);
     stage_issued();
   }
 
-  half8 FA[4], FBv[2];
-  auto read_frags = [&](const uint4* slot, int kk) __attribute__((always_inline)) {
+  half8 FA[kTwoPhase ? 2 : 1][4], FBv[kTwoPhase ? 2 : 1][2];
+  auto read_frags = [&](const uint4* slot, int kk, auto setc) __attribute__((always_inline)) {
+    constexpr int set = decltype(setc)::value;
     if constexpr (!(DIAG & 2)) {
 #pragma unroll
-      for (int a = 0; a < 4; ++a) FA[a] = as_half8(slot[(4 * wm + a) * 128 + 64 * kk]);
+      for (int a = 0; a < 4; ++a) FA[set][a] = as_half8(slot[(4 * wm + a) * 128 + 64 * kk]);
 #pragma unroll
-      for (int b = 0; b < 2; ++b) FBv[b] = as_half8(slot[1024 + (2 * wn + b) * 128 + 64 * kk]);
+      for (int b = 0; b < 2; ++b) FBv[set][b] = as_half8(slot[1024 + (2 * wn + b) * 128 + 64 * kk]);
     }
   };
+  // DIAG bit 6 (64): s_memtime stamps around every barrier of block 1's first 16 stages, waves 0 and 4 of workgroup 0,
+  // parked in the unused half of the bias area and copied out at the end (stamps[wave >> 2][stage][8]: entry and exit of the
+  // stage's phase barriers).  Valid results; the stamps cost a few per cent.
+  uint32_t stamp_it = 0, stamp_st = 0;
+  auto stamp = [&](int idx) __attribute__((always_inline)) {
+    if constexpr (DIAG & 64) {
+      if (blockIdx.x == 0 && (wave & 3) == 0 && stamp_it == 1u && stamp_st < 16u) {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        if (lane == 0) reinterpret_cast<unsigned long long*>(bias_lds + 2048)[(((uint32_t)wave >> 2) * 16u + stamp_st) * 8u + (uint32_t)idx] = t;
+      }
+    }
+  };
+  int phase_no = 0;
   auto phase_end = [&]() __attribute__((always_inline)) {
+    stamp(2 * (phase_no & 3));
     if constexpr (!(DIAG & 4)) asm volatile("s_barrier" ::: "memory");
+    stamp(2 * (phase_no & 3) + 1);
+    phase_no += 1;
     __builtin_amdgcn_sched_barrier(0);   // nothing, MFMAs included, moves across a phase boundary
   };
   uint32_t q = 0;            // consumer stage
   uint32_t since_store = 2;  // stages since the last epilogue's 16 stores entered the vmcnt queue
-  // My pieces of stage q + 1 have landed when at most the younger operations are outstanding: the pair just issued for
-  // stage q + 3 and the four loads of stage q + 2, plus the previous block's 16 stores while they are younger than the
-  // stage awaited.
-  auto wait_next_stage = [&]() __attribute__((always_inline)) {
+  // Counted wait of a load phase (the previous block's 16 stores count while they are younger than the stage awaited).
+  // Four phases: my pieces of stage q + 1 have landed when at most the pair just issued for stage q + 3 and the four loads
+  // of stage q + 2 are outstanding.  Two phases: the fragments of stage q + 1 are read in THIS phase, so that stage was
+  // certified a phase ago and the wait is for stage q + 2: outstanding at most the four loads just issued for q + 4 and
+  // the four of q + 3.
+  auto wait_ahead = [&]() __attribute__((always_inline)) {
     if (nst < 4u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (since_store < 2u) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (kTwoPhase) {
+      if (since_store < 2u) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      if (since_store < 2u) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    }
   };
 
-  {  // stage 0 is certified here; stage 1 by the first stage's own wait
+  {  // prologue: stage 0 (two phases: and stage 1) certified here, the next one by the first stage's own wait
     if (nst < 4u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     phase_end();
-    read_frags(reinterpret_cast<const uint4*>(ring) + lane, 0);
+    read_frags(reinterpret_cast<const uint4*>(ring) + lane, 0, IC<0>{});
+    if constexpr (kTwoPhase) read_frags(reinterpret_cast<const uint4*>(ring) + lane, 1, IC<1>{});
   }
   if constexpr (DIAG & 2) {
 #pragma unroll
-    for (int a = 0; a < 4; ++a) FA[a] = as_half8(reinterpret_cast<const uint4*>(bias_lds)[a * 64 + lane]);
-    FBv[0] = FA[1]; FBv[1] = FA[2];
+    for (int a = 0; a < 4; ++a) FA[0][a] = as_half8(reinterpret_cast<const uint4*>(bias_lds)[a * 64 + lane]);
+    FBv[0][0] = FA[0][1]; FBv[0][1] = FA[0][2];
+    if constexpr (kTwoPhase) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a) FA[1][a] = FA[0][a];
+      FBv[1][0] = FA[0][2]; FBv[1][1] = FA[0][1];
+    }
   }
-  // Both halves run the SAME phase sequence (MFMA k0 | load | MFMA k1 | load); waves 4-7 run it one phase late, which
-  // is what makes the roles alternate.  They pay the offset with one barrier here, waves 0-3 with one at the very end.
+  // Both halves run the SAME phase sequence; waves 4-7 run it one phase late, which is what makes the roles alternate.
+  // They pay the offset with one barrier here, waves 0-3 with one at the very end.
   if (second) phase_end();
 
   for (uint32_t it = 0;; ++it) {
@@ -197,43 +233,65 @@ __global__ __launch_bounds__(512, 2) void nifg_layer_kernel(const NifGemmParams 
     f32x16 acc[4][2];
 #pragma unroll
     for (int a = 0; a < 4; ++a) { acc[a][0] = (f32x16)(0.0f); acc[a][1] = (f32x16)(0.0f); }
+    auto multiply = [&](auto setc) __attribute__((always_inline)) {
+      constexpr int set = decltype(setc)::value;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(FA[set][a], FBv[set][0], acc[a][0], 0, 0, 0);
+        acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(FA[set][a], FBv[set][1], acc[a][1], 0, 0, 0);
+      }
+    };
 
     for (uint32_t st = 0; st < nst; ++st) {
       const uint4* slot = reinterpret_cast<const uint4*>(ring + (q % R) * kGemmStageBytes) + lane;
       const uint4* next = reinterpret_cast<const uint4*>(ring + ((q + 1u) % R) * kGemmStageBytes) + lane;
       q += 1;
       const bool two = kGemmKps * st + 1u < nks;   // (an odd k-step count: the last stage has one k-step)
-      // ---- MFMA phase, k-step 0
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(FA[a], FBv[0], acc[a][0], 0, 0, 0);
-        acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(FA[a], FBv[1], acc[a][1], 0, 0, 0);
-      }
-      __builtin_amdgcn_s_setprio(0);
-      phase_end();
-      // ---- load phase: weights of the stage three ahead, certify my share of the next stage, fragments of k-step 1
-      issue_pair(0);
-      wait_next_stage();
-      read_frags(slot, 1);
-      phase_end();
-      // ---- MFMA phase, k-step 1
-      if (two) {
+      stamp_it = it; stamp_st = st; phase_no = 0;
+      if constexpr (kTwoPhase) {
+        // ---- MFMA phase: both k-steps of the stage
         __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-          acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(FA[a], FBv[0], acc[a][0], 0, 0, 0);
-          acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(FA[a], FBv[1], acc[a][1], 0, 0, 0);
-        }
+        multiply(IC<0>{});
+        if (two) multiply(IC<1>{});
         __builtin_amdgcn_s_setprio(0);
+        phase_end();
+        // ---- load phase: both pairs of the stage four ahead (into the slot of the stage just multiplied: its fragments are
+        // in registers, and the partner half drained its reads of it before the barrier that started this phase), certify
+        // my share of the stage two ahead, all twelve fragments of the next stage; the reads are drained before the
+        // phase ends, so the next phase's loads may overwrite their slot
+        issue_pair(0);
+        issue_pair(1);
+        stage_issued();
+        wait_ahead();
+        read_frags(next, 0, IC<0>{});
+        read_frags(next, 1, IC<1>{});
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        phase_end();
+      } else {
+        // ---- MFMA phase, k-step 0
+        __builtin_amdgcn_s_setprio(1);
+        multiply(IC<0>{});
+        __builtin_amdgcn_s_setprio(0);
+        phase_end();
+        // ---- load phase: weights of the stage three ahead, certify my share of the next stage, fragments of k-step 1
+        issue_pair(0);
+        wait_ahead();
+        read_frags(slot, 1, IC<0>{});
+        phase_end();
+        // ---- MFMA phase, k-step 1
+        if (two) {
+          __builtin_amdgcn_s_setprio(1);
+          multiply(IC<0>{});
+          __builtin_amdgcn_s_setprio(0);
+        }
+        phase_end();
+        // ---- load phase: activations of the stage three ahead, fragments of the next stage's k-step 0 (certified by the
+        // barrier that ended this wave's previous load phase at the latest)
+        issue_pair(1);
+        stage_issued();
+        read_frags(next, 0, IC<0>{});
+        phase_end();
       }
-      phase_end();
-      // ---- load phase: activations of the stage three ahead, fragments of the next stage's k-step 0 (certified by the
-      // barrier that ended this wave's previous load phase at the latest)
-      issue_pair(1);
-      stage_issued();
-      read_frags(next, 0);
-      phase_end();
       since_store += 1;
     }
 
@@ -267,8 +325,15 @@ __global__ __launch_bounds__(512, 2) void nifg_layer_kernel(const NifGemmParams 
     }
     since_store = 0;
   }
+  stamp_st = 99;
   if (!second) phase_end();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the run-ahead loads before the wave ends
+  if constexpr (DIAG & 64) {
+    if (blockIdx.x == 0 && (wave & 3) == 0 && P.stamps && nst >= 16u) {
+      const unsigned long long* src = reinterpret_cast<const unsigned long long*>(bias_lds + 2048) + ((uint32_t)wave >> 2) * 128u;
+      for (int i = lane; i < 128; i += 64) P.stamps[((uint32_t)wave >> 2) * 128u + i] = src[i];
+    }
+  }
 }
 
 // tile_start[r] = first 32-sample tile of queue region r; tile_start[n_regions] = total.  One workgroup.

@@ -122,6 +122,7 @@ struct pt_context {
   uint4* d_gemm_feat = nullptr;
   uint32_t* d_tile_start = nullptr;
   uint32_t gemm_chunk = 0;   // 32-sample tiles per chunk (multiple of 8); 0 = path not set up
+  unsigned long long* d_stamps = nullptr;   // profiling build: 256 phase stamps of the wide-NIF layer kernel
 
   // stats
   pt_stats stats{};
@@ -631,7 +632,21 @@ int launch_nif_gemm(pt_handle h, const ptd::NifParams& N) {
     switch (gdiag) {
       case 1: PT_LAYER(ptd::nifg_layer_kernel<1>, 512); case 2: PT_LAYER(ptd::nifg_layer_kernel<2>, 512);
       case 3: PT_LAYER(ptd::nifg_layer_kernel<3>, 512); case 4: PT_LAYER(ptd::nifg_layer_kernel<4>, 512);
-      case 8: PT_LAYER(ptd::nifg_layer_kernel<8>, 512); default: break;
+      case 8: PT_LAYER(ptd::nifg_layer_kernel<8>, 512);
+      case 128: PT_LAYER(ptd::nifg_layer_kernel<128>, 512);   // two phases per stage (valid results)
+      case 64: case 192: {   // stamped builds, four / two phases per stage (valid results): the stamps of the LAST layer launch are read by pt_diag_stamps
+        ptd::NifGemmParams GS = G;
+        GS.stamps = h->d_stamps;
+        if (gdiag == 64) {
+          PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ptd::nifg_layer_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, ptd::kGemmLdsBytes));
+          hipLaunchKernelGGL(ptd::nifg_layer_kernel<64>, dim3(grid), dim3(512), ptd::kGemmLdsBytes, h->stream, GS);
+        } else {
+          PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ptd::nifg_layer_kernel<192>), hipFuncAttributeMaxDynamicSharedMemorySize, ptd::kGemmLdsBytes));
+          hipLaunchKernelGGL(ptd::nifg_layer_kernel<192>, dim3(grid), dim3(512), ptd::kGemmLdsBytes, h->stream, GS);
+        }
+        return PT_OK;
+      }
+      default: break;
     }
 #undef PT_LAYER
     hipLaunchKernelGGL(ptd::nifg_layer_kernel<0>, dim3(grid), dim3(512), ptd::kGemmLdsBytes, h->stream, G);
@@ -836,6 +851,7 @@ int pt_destroy(pt_handle h) {
   (void)hipFree(h->d_counters);
   (void)hipFree(h->d_wpack); (void)hipFree(h->d_bpack);
   (void)hipFree(h->d_gemm_act[0]); (void)hipFree(h->d_gemm_act[1]); (void)hipFree(h->d_gemm_feat); (void)hipFree(h->d_tile_start);
+  (void)hipFree(h->d_stamps);
   (void)hipFree(h->d_scratch);
   (void)hipFree(h->d_hdr_stage); (void)hipFree(h->d_hdr_gather); (void)hipFree(h->d_film);
   if (h->comm) (void)ncclCommDestroy(h->comm);
@@ -932,6 +948,9 @@ int pt_upload_nif(pt_handle h, const pt_layer* layers, uint32_t n_layers, uint32
     h->d_gemm_feat = nullptr;
     PT_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_gemm_feat), feat_bytes));
     if (!h->d_tile_start) PT_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_tile_start), (ptd::kMaxRegions + 1) * 4));
+#ifdef PTMI_DIAG_BUILD
+    if (!h->d_stamps) { PT_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_stamps), 256 * 8)); PT_HIP(hipMemset(h->d_stamps, 0, 256 * 8)); }
+#endif
     h->gemm_chunk = chunk;
   }
   h->nif = N;
@@ -1345,6 +1364,17 @@ int pt_gather_hdr(pt_handle h, int32_t source, size_t slot_items, float* root_ho
   PT_HIP(hipStreamSynchronize(h->stream));   // host buffer is not touched after return
   return PT_OK;
 }
+
+#ifdef PTMI_DIAG_BUILD
+// profiling build only: copy the 256 phase stamps of the last stamped layer launch (PTMI_GEMM_DIAG=64)
+int pt_diag_stamps(pt_handle h, unsigned long long* out256) {
+  if (!h || !h->d_stamps || !out256) return PT_ERR_INVALID_ARGUMENT;
+  PT_HIP(hipSetDevice(h->cfg.device));
+  PT_HIP(hipStreamSynchronize(h->stream));
+  PT_HIP(hipMemcpy(out256, h->d_stamps, 256 * 8, hipMemcpyDeviceToHost));
+  return PT_OK;
+}
+#endif
 
 int pt_comm_info(pt_handle h, int* rank, int* world) {
   if (!h) return PT_ERR_INVALID_ARGUMENT;

@@ -387,3 +387,20 @@ def test_interactive_restart_and_nif_hot_reload_over_the_ui_port(host, tmp_path)
     assert "Interaction stopped reverting samples per step to: 20" in log
     assert got["hdr_header"] == (W, H, H) and got["preview"] >= 8 and got["rates"] >= 8
     assert os.path.getsize(out) > 500                                                            # the last film is left on disk
+
+
+@pytest.mark.gpu
+def test_cli_on_the_reference_assets_directory(host, tmp_path):
+    """`--assets` pointed at the reference's own assets.extra (only nif_metadata.txt is shipped: the trained weights are
+    absent, so `--synthetic-nif` supplies seeded stand-ins of the architecture the metadata names: 6 x 320, embedding 12)."""
+    exe = os.path.join(HOST, "ipu_trace")
+    out = tmp_path / "alley.png"
+    r = subprocess.run([exe, "--assets", os.path.dirname(REAL_META), "--synthetic-nif", "-w", "48", "-h", "32", "-s", "4",
+                        "--samples-per-step", "2", "-o", str(out), "--log-level", "debug"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "NIF embedding dimension: 12" in r.stdout and "NIF hidden dimension: 320" in r.stdout
+    assert "model FLOPS: %d" % (1089283 * 48 * 32) in r.stdout           # NifModel::analyseModel's formula on 6 x 320
+    assert os.path.getsize(out) > 300 and os.path.getsize(tmp_path / "alley.exr") > 48 * 32 * 3 * 2
+    # without stand-in weights the run fails the way the reference does when converted.hdf5 is missing
+    r = subprocess.run([exe, "--assets", os.path.dirname(REAL_META), "-w", "48", "-h", "32", "-o", str(out)], capture_output=True, text=True)
+    assert r.returncode == 1 and "Could not load NIF model" in r.stdout
