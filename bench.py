@@ -156,13 +156,21 @@ def main():
     # back to torch.distributed's gather of the same device buffers and the bench line says so.
     product_gather = False
     if world > 1 and not rehearsal:
-        ok, why = 1, ""
-        try:
-            ids = [ptmi.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)
-            r.comm_init_rank(ids[0], rank, world)
-        except Exception as e:   # noqa: BLE001 -- any failure means "use the fallback", on every rank
-            ok, why = 0, str(e)
+        ok, why, uid = 1, "", None
+        if rank == 0:
+            try:
+                uid = ptmi.comm_unique_id()
+            except Exception as e:   # noqa: BLE001 -- the other ranks still have to be told (they wait in the broadcast)
+                why = str(e)
+        ids = [uid]
+        dist.broadcast_object_list(ids, src=0)
+        if ids[0] is None:
+            ok = 0
+        else:
+            try:
+                r.comm_init_rank(ids[0], rank, world)
+            except Exception as e:   # noqa: BLE001 -- any failure means "use the fallback", on every rank
+                ok, why = 0, str(e)
         flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         product_gather = bool(flag.item())
