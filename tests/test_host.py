@@ -404,3 +404,21 @@ def test_cli_on_the_reference_assets_directory(host, tmp_path):
     # without stand-in weights the run fails the way the reference does when converted.hdf5 is missing
     r = subprocess.run([exe, "--assets", os.path.dirname(REAL_META), "-w", "48", "-h", "32", "-o", str(out)], capture_output=True, text=True)
     assert r.returncode == 1 and "Could not load NIF model" in r.stdout
+
+
+@pytest.mark.gpu
+def test_cli_two_devices_or_a_clean_refusal(host, tmp_path):
+    """`--ipus 2`: on a box with two or more GPUs the film must equal the one-GPU film bit for bit (worklist slices per
+    device, RNG keyed by pixel and sample index, resident film gathered by pt_gather_hdr over an RCCL communicator of two
+    ranks made by pt_comm_init_all); on a one-GPU box the run must refuse cleanly instead of crashing."""
+    import torch
+    one, _ = _run_cli(host, tmp_path, "one_gpu", ["--ipus", "1"])
+    if torch.cuda.device_count() >= 2:
+        two, log = _run_cli(host, tmp_path, "two_gpus", ["--ipus", "2"])
+        assert "RCCL communicator over 2 devices" in log
+        assert two.tobytes() == one.tobytes()
+    else:
+        exe = os.path.join(HOST, "ipu_trace")
+        r = subprocess.run([exe, "--assets", str(tmp_path / "assets.extra"), "-w", "96", "-h", "80", "-s", "8", "--samples-per-step", "4",
+                            "-o", str(tmp_path / "x.png"), "--ipus", "2"], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 1 and "Could not attach to device" in r.stdout and "out of range" in r.stdout
