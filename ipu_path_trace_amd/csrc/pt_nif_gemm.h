@@ -259,12 +259,12 @@ __global__ __launch_bounds__(512, 2) void nifg_layer_kernel(const NifGemmParams 
         // in registers, and the partner half drained its reads of it before the barrier that started this phase), certify
         // my share of the stage two ahead, all twelve fragments of the next stage; the reads are drained before the
         // phase ends, so the next phase's loads may overwrite their slot
+        read_frags(next, 0, IC<0>{});      // fragment reads first: their latency passes under the LDS-DMA issue and wait below
+        read_frags(next, 1, IC<1>{});
         issue_pair(0);
         issue_pair(1);
         stage_issued();
         wait_ahead();
-        read_frags(next, 0, IC<0>{});
-        read_frags(next, 1, IC<1>{});
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         phase_end();
       } else {
@@ -274,9 +274,11 @@ __global__ __launch_bounds__(512, 2) void nifg_layer_kernel(const NifGemmParams 
         __builtin_amdgcn_s_setprio(0);
         phase_end();
         // ---- load phase: weights of the stage three ahead, certify my share of the next stage, fragments of k-step 1
+        // (the fragment reads go first: issued right before the barrier, their LDS latency would open the next MFMA phase;
+        // here it passes under the LDS-DMA issue and the counted wait)
+        read_frags(slot, 1, IC<0>{});
         issue_pair(0);
         wait_ahead();
-        read_frags(slot, 1, IC<0>{});
         phase_end();
         // ---- MFMA phase, k-step 1
         if (two) {
@@ -287,9 +289,9 @@ __global__ __launch_bounds__(512, 2) void nifg_layer_kernel(const NifGemmParams 
         phase_end();
         // ---- load phase: activations of the stage three ahead, fragments of the next stage's k-step 0 (certified by the
         // barrier that ended this wave's previous load phase at the latest)
+        read_frags(next, 0, IC<0>{});
         issue_pair(1);
         stage_issued();
-        read_frags(next, 0, IC<0>{});
         phase_end();
       }
       since_store += 1;
