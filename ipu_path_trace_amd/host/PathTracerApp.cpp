@@ -350,11 +350,15 @@ void PathTracerApp::executeHostFilm(std::uint32_t steps) {
     if (uiServer && uiServer->stateChanged()) {
       state = uiServer->consumeState();
       const auto status = processUserInput(state, imageWidth, imageHeight);
+      // (the previous step's host task may still be sending to the client: join it before the server goes away -- the
+      // reference resets the server while that task can still be running)
       if (status == InterfaceServer::Status::Stop) {
+        hostProcessing.waitForCompletion();
         uiServer.reset();
         break;
       }
       if (status == InterfaceServer::Status::Disconnected) {
+        hostProcessing.waitForCompletion();
         uiServer.reset();
       } else if (status == InterfaceServer::Status::Restart) {
         step = 1;
