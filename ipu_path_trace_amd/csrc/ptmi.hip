@@ -632,7 +632,7 @@ int launch_nif_gemm(pt_handle h, const ptd::NifParams& N) {
     switch (gdiag) {
       case 1: PT_LAYER(ptd::nifg_layer_kernel<1>, 512); case 2: PT_LAYER(ptd::nifg_layer_kernel<2>, 512);
       case 3: PT_LAYER(ptd::nifg_layer_kernel<3>, 512); case 4: PT_LAYER(ptd::nifg_layer_kernel<4>, 512);
-      case 8: PT_LAYER(ptd::nifg_layer_kernel<8>, 512);
+      case 8: PT_LAYER(ptd::nifg_layer_kernel<8>, 512); case 16: PT_LAYER(ptd::nifg_layer_kernel<16>, 512);
       case 128: PT_LAYER(ptd::nifg_layer_kernel<128>, 512);   // two phases per stage (valid results)
       case 64: case 192: {   // stamped builds, four / two phases per stage (valid results): the stamps of the LAST layer launch are read by pt_diag_stamps
         ptd::NifGemmParams GS = G;
