@@ -136,7 +136,10 @@ int pt_set_render_settings(pt_handle h, uint64_t seed, float aa_noise_scale, flo
 /* Program "setup" (PathTracerApp.cpp:481): host -> device copy of the active worklist. */
 int pt_setup(pt_handle h, const pt_trace_record* work, size_t n);
 /* Program "path_trace" (PathTracerApp.cpp:482): samples_per_step iterations of
- * K2..K12 on the device (PathTracerApp.cpp:432-468).  Blocks until the device is done. */
+ * K2..K12 on the device (PathTracerApp.cpp:432-468).  Blocks until the device is done.
+ * On failure every stream of the handle has been drained before the call returns (nothing is
+ * left running on buffers the caller may free), the sample sequence has not advanced, and the
+ * worklist's accumulators are undefined: call pt_setup again before the next path_trace. */
 int pt_path_trace(pt_handle h);
 /* Program "read_results" (PathTracerApp.cpp:483): device -> host copy of the worklist plus stats. */
 int pt_read_results(pt_handle h, pt_trace_record* work, size_t n, pt_stats* stats);

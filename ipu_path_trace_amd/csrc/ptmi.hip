@@ -1057,6 +1057,12 @@ static int enqueue_path_trace(pt_handle h, std::vector<StageSpan>& spans, size_t
       N.region_cap = g.region_cap;
       N.rad_r = B.rad_r; N.rad_g = B.rad_g; N.rad_b = B.rad_b;
       N.out_bgr = nullptr;
+      // Fault injection for the error-path test (tests/test_gpu_edge_cases.py): PTMI_FAULT_INJECT=nif_launch:<batch> makes
+      // that batch's NIF launch report a failure after the earlier batches are already queued on all three streams.
+      if (const char* fi = getenv("PTMI_FAULT_INJECT")) {
+        if (!strncmp(fi, "nif_launch:", 11) && (uint32_t)atoi(fi + 11) == batch)
+          return fail(h, PT_ERR_HIP, "injected fault: NIF launch of batch " + std::to_string(batch));
+      }
       if (int rc = launch_nif(h, N, h->n_cus)) return rc;
       spans.push_back({ev + 2, ev + 3, 1});
       h->stats.nif_launches += 1;

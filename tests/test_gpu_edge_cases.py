@@ -187,3 +187,37 @@ def test_rccl_gather_of_hdr_tiles_single_rank(ptmi_lib):
     with pytest.raises(ptmi_lib.PtError):
         r.comm_init_rank(ptmi_lib.comm_unique_id(), 0, 1)            # one communicator per handle
     r.close()
+
+
+def test_failed_path_trace_drains_and_the_handle_stays_usable(oracle, ptmi_lib):
+    """A launch failure in the MIDDLE of the batch loop (injected: PTMI_FAULT_INJECT) must come back as an error with all
+    three streams drained -- the earlier batches are already queued when it happens -- must not advance the sample
+    sequence, and must leave the handle usable: after a fresh setup the same step gives the oracle's result."""
+    import os
+    O = oracle
+    W = H = 48
+    L, mx, mean = _nif()
+    r = ptmi_lib.Renderer(W, H, max_path_length=6, iterations_per_batch=2)      # 6 spp = 3 batches
+    r.init_nif_weights(L, 12, mx, mean)
+    r.init_render_settings(samples_per_step=6)
+    rec = ptmi_lib.worklist(W, H)
+    r.setup(rec)
+    os.environ["PTMI_FAULT_INJECT"] = "nif_launch:1"
+    try:
+        with pytest.raises(ptmi_lib.PtError) as e:
+            r.path_trace()
+        assert e.value.code == -3 and "injected fault" in str(e.value)
+    finally:
+        del os.environ["PTMI_FAULT_INJECT"]
+    r.synchronize()                                                             # nothing left running
+    rec = ptmi_lib.worklist(W, H)
+    r.setup(rec)                                                                # accumulators are undefined after a failure
+    r.path_trace()                                                              # same sample indices 0..5 as the failed step
+    st = r.read_results(rec)
+    cfg = O.make_config(width=W, height=H, max_path_length=6, env_mode=O.ENV_NIF)
+    ref = O.worklist(W, H)
+    ost = O.render(cfg, O.Nif(L, 12, mx, mean), ref, 0, 6)
+    assert np.array_equal(rec["pathLength"], ref["pathLength"]) and (st.paths, st.segments, st.escaped) == (ost.paths, ost.segments, ost.escaped)
+    for c in "rgb":
+        np.testing.assert_allclose(rec[c], ref[c], rtol=2e-2, atol=1e-6)
+    r.close()
