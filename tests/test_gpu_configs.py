@@ -217,3 +217,49 @@ def test_redeal_by_measured_path_length_keeps_the_film(ptmi_lib):
         return per_rank.max() / per_rank.mean()
     assert imbalance(dealt) <= imbalance(static) + 1e-9
     assert np.bincount(dealt, minlength=world).max() - np.bincount(dealt, minlength=world).min() <= 1
+
+
+def _same_render_subset(O, rec, n_pixels, W, H, depth, spp, layers, seed, min_row=0):
+    """Records of `n_pixels` pixels picked FROM a finished full-size render, and the oracle's records for the same pixels."""
+    rng = np.random.default_rng(seed)
+    idx = rng.choice(np.flatnonzero(rec["v"] >= min_row), n_pixels, replace=False)
+    ref = np.zeros(n_pixels, dtype=rec.dtype)
+    ref["u"], ref["v"] = rec["u"][idx], rec["v"][idx]
+    meta = nif_assets.URBAN_ALLEY_META
+    cfg = O.make_config(width=W, height=H, max_path_length=depth, env_mode=O.ENV_NIF)
+    O.render(cfg, O.Nif(layers, 12, meta["max"], nif_assets.folded_mean()), ref, 0, spp)
+    return rec[idx], ref
+
+
+@pytest.mark.parametrize("name,W,H,depth,spp,hidden,nlayers,n_check", [
+    ("C2", 1104, 1000, 8, 300, 320, 6, 400),      # BASELINE configs[1] at its stated size and samples per step
+    ("C3", 3840, 2160, 16, 1000, 320, 6, 120),    # configs[2]: 8.3 G path-samples in one step, depth 16
+    ("C5", 1104, 1000, 8, 300, 1024, 8, 40),      # configs[4]: NIF 8x1024
+])
+def test_configs_at_their_stated_sizes_and_sample_counts(oracle, ptmi_lib, name, W, H, depth, spp, hidden, nlayers, n_check):
+    """The BASELINE configurations as stated (full image, full samples per step, their NIF), one step each: size-independent
+    properties over every work item, and the oracle on a random subset of pixels taken from that same render (path structure
+    identical, radiance within the stated NIF tolerance).  (configs[3] is configs[1]'s image over 8 GPUs: no such box.)"""
+    layers = nif_assets.synthetic_nif(hidden=hidden, layer_count=nlayers, seed=2024 if hidden == 320 else 31)
+    meta = nif_assets.URBAN_ALLEY_META
+    r = ptmi_lib.Renderer(W, H, max_path_length=depth)
+    r.init_nif_weights(layers, 12, meta["max"], nif_assets.folded_mean())
+    r.init_render_settings(samples_per_step=spp)
+    work = ptmi_lib.worklist(W, H)
+    r.setup(work)
+    r.path_trace()
+    st = r.read_results(work)
+    r.close()
+    assert st.paths == W * H * spp and st.nif_launches >= 1
+    assert np.all(work["sampleCount"] == spp)
+    assert work["pathLength"].min() >= spp and work["pathLength"].max() <= depth * spp     # uint16 holds spp x depth here
+    assert int(work["pathLength"].astype(np.int64).sum()) == st.segments
+    assert 0.90 < st.escaped / st.paths < 0.97
+    img = np.stack([work["r"], work["g"], work["b"]], -1)
+    assert np.all(np.isfinite(img)) and img.min() >= 0
+    sky = work["v"] < H // 3                                              # camera looks along -z: the upper third only sees sky
+    assert np.all(work["pathLength"][sky] == spp) and np.all(work["r"][sky] > 0)
+    got, ref = _same_render_subset(oracle, work, n_check, W, H, depth, spp, layers, seed={"C2": 2, "C3": 3, "C5": 5}[name], min_row=H // 3)
+    assert np.array_equal(got["pathLength"], ref["pathLength"]), name
+    for c in "rgb":
+        np.testing.assert_allclose(got[c], ref[c], rtol=NIF_RTOL, atol=1e-5, err_msg=name)
