@@ -111,9 +111,11 @@ def test_config_c3_4k_deep_paths(oracle, ptmi_lib):
 
 
 def test_config_c4_partition_invariance(ptmi_lib):
-    """C4 shards the image over 8 ranks: each rank's tiles rendered separately reassemble to the single-GPU image
-    bit for bit (RNG keyed by pixel; no data-path collective)."""
-    W, H, depth, spp, world = 320, 200, 8, 6, 8
+    """C4 shards the 1104x1000 image over 8 ranks: each rank's tiles (its real share: 16x16 tiles dealt round-robin),
+    rendered separately on this GPU and handed over through pt_gather_hdr, reassemble to the single-GPU image bit for bit
+    (RNG keyed by pixel; no data-path collective).  Full image size, reduced sample count; the 8-GPU run itself needs an
+    8-GPU box."""
+    W, H, depth, spp, world = 1104, 1000, 8, 6, 8
     layers = nif_assets.synthetic_nif()
     meta = nif_assets.URBAN_ALLEY_META
     whole = partition.tile_order_worklist(W, H)
@@ -124,7 +126,7 @@ def test_config_c4_partition_invariance(ptmi_lib):
     r.path_trace()
     r.read_results(whole)
     film = np.zeros((H, W, 3), np.float32)
-    film[whole["v"], whole["u"]] = np.stack([whole["b"], whole["g"], whole["r"]], -1) / spp
+    film[whole["v"], whole["u"]] = np.stack([whole["b"], whole["g"], whole["r"]], -1) * (np.float32(1.0) / np.float32(spp))
     parts = []
     for rank in range(world):
         rec = partition.tile_order_worklist(W, H, rank, world)
@@ -132,8 +134,10 @@ def test_config_c4_partition_invariance(ptmi_lib):
         r.init_render_settings(seed=1, samples_per_step=spp)          # restart the sample sequence per "rank"
         r.setup(rec)
         r.path_trace()
+        slot = partition.max_items_per_rank(W, H, world)
+        parts.append(r.gather_hdr(slot)[0])                            # the product's hand-off (degenerate at one rank)
         r.read_results(rec)
-        parts.append(np.stack([rec["b"], rec["g"], rec["r"]], -1) / np.float32(spp))
+        np.testing.assert_array_equal(parts[-1][: rec.size], np.stack([rec["b"], rec["g"], rec["r"]], -1) * (np.float32(1.0) / np.float32(spp)))
     assert np.array_equal(partition.assemble_hdr(W, H, world, parts), film)
     r.close()
 
