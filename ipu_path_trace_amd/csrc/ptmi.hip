@@ -84,6 +84,7 @@ struct pt_context {
   // batch buffers, double-buffered: the trace kernel of batch b+1 runs on `trace_stream` while the NIF
   // kernel of batch b (MFMA-bound) runs on `stream`
   uint32_t iters_per_batch = 1;
+  uint32_t first_batch_iters = 1;   // iterations of a step's first batch (see enqueue_path_trace)
   size_t batch_paths_cap = 0;
   size_t queue_cap = 0;
   struct BatchBuffers {
@@ -804,6 +805,7 @@ int pt_create(const pt_config* cfg, pt_handle* out) {
   if ((uint64_t)k * n >= (1ull << 31)) k = (uint32_t)(((1ull << 31) - 1) / n);
   if (k == 0) { h->error = "max_work_items too large"; return bail(PT_ERR_INVALID_ARGUMENT); }
   h->iters_per_batch = k;
+  if (const char* e = getenv("PTMI_FIRST_BATCH")) h->first_batch_iters = (uint32_t)std::max(1, atoi(e));   // tuning knob, default 1
   h->batch_paths_cap = (size_t)k * n;
 
   PT_HIPC(dev_alloc(&h->d_records, n));
@@ -1027,7 +1029,10 @@ static int enqueue_path_trace(pt_handle h, std::vector<StageSpan>& spans, size_t
   PT_HIP(hipStreamWaitEvent(h->trace_stream, e_begin, 0));   // counters memset and earlier work on `stream`
   uint32_t done = 0, batch = 0;
   while (done < h->samples_per_step) {
-    const uint32_t iters = std::min(h->iters_per_batch, h->samples_per_step - done);
+    // The first batch is kept short when the step has several: its trace kernel is the only one with no NIF kernel to
+    // hide under, so the sooner it ends the sooner the MFMA pipes start (per-pixel sums stay in iteration order).
+    uint32_t iters = std::min(h->iters_per_batch, h->samples_per_step - done);
+    if (batch == 0 && !h->env_const && h->samples_per_step > 2u * h->iters_per_batch) iters = std::min(iters, h->first_batch_iters);
     const uint32_t total = iters * n;
     const TraceGrid g = trace_grid(total);
     pt_context::BatchBuffers& B = h->bb[batch & 1];
