@@ -18,8 +18,8 @@
 #include "pt_nif.h"
 #include "pt_nif_gemm.h"
 #ifdef PTMI_DIAG_BUILD
-#include "pt_nif16.h"
-#include "pt_nif_variants.h"
+#include "diag/pt_nif16.h"
+#include "diag/pt_nif_variants.h"
 #endif
 #include "pt_trace.h"
 
@@ -124,6 +124,7 @@ struct pt_context {
   uint32_t* d_tile_start = nullptr;
   uint32_t gemm_chunk = 0;   // 32-sample tiles per chunk (multiple of 8); 0 = path not set up
   unsigned long long* d_stamps = nullptr;   // profiling build: 256 phase stamps of the wide-NIF layer kernel
+  int diag_fault_batch = -1;                // test build: batch whose NIF launch fails (pt_diag_inject_fault), -1 = none
 
   // stats
   pt_stats stats{};
@@ -805,7 +806,9 @@ int pt_create(const pt_config* cfg, pt_handle* out) {
   if ((uint64_t)k * n >= (1ull << 31)) k = (uint32_t)(((1ull << 31) - 1) / n);
   if (k == 0) { h->error = "max_work_items too large"; return bail(PT_ERR_INVALID_ARGUMENT); }
   h->iters_per_batch = k;
-  if (const char* e = getenv("PTMI_FIRST_BATCH")) h->first_batch_iters = (uint32_t)std::max(1, atoi(e));   // tuning knob, default 1
+#ifdef PTMI_DIAG_BUILD
+  if (const char* e = getenv("PTMI_FIRST_BATCH")) h->first_batch_iters = (uint32_t)std::max(1, atoi(e));   // tuning sweep of the profiling build; the product uses 1
+#endif
   h->batch_paths_cap = (size_t)k * n;
 
   PT_HIPC(dev_alloc(&h->d_records, n));
@@ -1062,12 +1065,12 @@ static int enqueue_path_trace(pt_handle h, std::vector<StageSpan>& spans, size_t
       N.region_cap = g.region_cap;
       N.rad_r = B.rad_r; N.rad_g = B.rad_g; N.rad_b = B.rad_b;
       N.out_bgr = nullptr;
-      // Fault injection for the error-path test (tests/test_gpu_edge_cases.py): PTMI_FAULT_INJECT=nif_launch:<batch> makes
-      // that batch's NIF launch report a failure after the earlier batches are already queued on all three streams.
-      if (const char* fi = getenv("PTMI_FAULT_INJECT")) {
-        if (!strncmp(fi, "nif_launch:", 11) && (uint32_t)atoi(fi + 11) == batch)
-          return fail(h, PT_ERR_HIP, "injected fault: NIF launch of batch " + std::to_string(batch));
-      }
+#ifdef PTMI_DIAG_BUILD
+      // Fault injection for the error-path test (tests/test_gpu_edge_cases.py), test build only: pt_diag_inject_fault(h, b)
+      // makes batch b's NIF launch report a failure after the earlier batches are already queued on all three streams.
+      if (h->diag_fault_batch >= 0 && (uint32_t)h->diag_fault_batch == batch)
+        return fail(h, PT_ERR_HIP, "injected fault: NIF launch of batch " + std::to_string(batch));
+#endif
       if (int rc = launch_nif(h, N, h->n_cus)) return rc;
       spans.push_back({ev + 2, ev + 3, 1});
       h->stats.nif_launches += 1;
@@ -1377,6 +1380,13 @@ int pt_gather_hdr(pt_handle h, int32_t source, size_t slot_items, float* root_ho
 }
 
 #ifdef PTMI_DIAG_BUILD
+// test build only: the NIF launch of batch `batch` of every following pt_path_trace fails (batch < 0: off)
+int pt_diag_inject_fault(pt_handle h, int32_t batch) {
+  if (!h) return PT_ERR_INVALID_ARGUMENT;
+  h->diag_fault_batch = batch;
+  return PT_OK;
+}
+
 // profiling build only: copy the 256 phase stamps of the last stamped layer launch (PTMI_GEMM_DIAG=64)
 int pt_diag_stamps(pt_handle h, unsigned long long* out256) {
   if (!h || !h->d_stamps || !out256) return PT_ERR_INVALID_ARGUMENT;

@@ -58,15 +58,15 @@ class Stats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
 
 
-_lib = None
+_libs = {}
 
 
-def load_library():
-    """Load libptmi.so.  Raises if it has not been built: the product path has no fallback."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    path = library_path()
+def load_library(diag=False):
+    """Load libptmi.so (the product).  Raises if it has not been built: the product path has no fallback.
+    diag=True loads libptmi_diag.so, the profiling / test build (only tests/ and scripts/ ask for it)."""
+    if diag in _libs:
+        return _libs[diag]
+    path = library_path(diag)
     if not os.path.exists(path):
         raise FileNotFoundError(
             "%s not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()')" % path)
@@ -101,7 +101,10 @@ def load_library():
     L.pt_synchronize.argtypes = [C.c_void_p]
     L.pt_nif_infer.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     L.pt_trace_paths.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
-    _lib = L
+    if diag:
+        L.pt_diag_inject_fault.argtypes = [C.c_void_p, C.c_int32]
+        L.pt_diag_stamps.argtypes = [C.c_void_p, C.c_void_p]
+    _libs[diag] = L
     return L
 
 
@@ -120,8 +123,8 @@ class Renderer:
 
     def __init__(self, width, height, max_work_items=None, max_path_length=10, roulette_depth=3, stop_prob=0.3,
                  refractive_index=1.5, aa_noise_type=AA_NORMAL, sample_precision=SAMPLES_HALF, device=0,
-                 iterations_per_batch=0, stream=None):
-        self._lib = load_library()
+                 iterations_per_batch=0, stream=None, diag=False):
+        self._lib = load_library(diag)
         cfg = Config()
         cfg.struct_size = C.sizeof(Config)
         cfg.width, cfg.height = width, height

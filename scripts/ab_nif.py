@@ -1,5 +1,5 @@
 """Interleaved A/B of NIF kernel variants of the profiling build, in ONE process on one device (cdna_hip_programming.md
-section 5.4 rule 24).  usage: PTMI_LIBRARY=ipu_path_trace_amd/libptmi_diag.so python scripts/ab_nif.py [rounds] [spp] name=ENV:VAL ...
+section 5.4 rule 24).  usage (always loads libptmi_diag.so): python scripts/ab_nif.py [rounds] [spp] name=ENV:VAL ...
 e.g.  v3= v2w8=PTMI_NIF_VARIANT:3 v2w4x64=PTMI_NIF_VARIANT:2
 Prints per variant the NIF TFLOP/s (escaped x FLOP / sum of NIF-kernel HIP-event time) and Mpath-samples/s of every round."""
 import os
@@ -21,7 +21,7 @@ for a in args:
 hidden = int(os.environ.get("AB_HIDDEN", "320"))
 layers = int(os.environ.get("AB_LAYERS", "6"))
 W, H = 1104, 1000
-r = ptmi.Renderer(W, H, max_path_length=8)
+r = ptmi.Renderer(W, H, max_path_length=8, diag=True)
 r.init_nif_weights(A.synthetic_nif(hidden=hidden, layer_count=layers), 12, A.URBAN_ALLEY_META["max"], A.folded_mean())
 r.init_render_settings(samples_per_step=spp)
 rec = ptmi.worklist(W, H)

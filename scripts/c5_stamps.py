@@ -1,5 +1,5 @@
 """Phase timing of the wide-NIF layer kernel from in-kernel s_memtime stamps (profiling build, PTMI_GEMM_DIAG=64).
-usage: PTMI_LIBRARY=ipu_path_trace_amd/libptmi_diag.so python scripts/c5_stamps.py
+usage (always loads libptmi_diag.so): python scripts/c5_stamps.py
 Prints, for waves 0 and 4 of workgroup 0 over 16 stages of a hidden layer's second block: cycles from leaving a barrier to
 reaching the next (the phase's own work) and cycles spent waiting in each barrier."""
 import ctypes as C
@@ -14,7 +14,7 @@ NPH = 2 if os.environ["PTMI_GEMM_DIAG"] == "192" else 4
 from ipu_path_trace_amd import nif_assets as A, ptmi  # noqa: E402
 
 W, H = 1104, 1000
-r = ptmi.Renderer(W, H, max_path_length=8)
+r = ptmi.Renderer(W, H, max_path_length=8, diag=True)
 r.init_nif_weights(A.synthetic_nif(hidden=1024, layer_count=8), 12, A.URBAN_ALLEY_META["max"], A.folded_mean())
 r.init_render_settings(samples_per_step=8)
 rec = ptmi.worklist(W, H)
@@ -22,8 +22,7 @@ r.setup(rec)
 r.path_trace()
 r.path_trace()
 out = (C.c_ulonglong * 256)()
-lib = ptmi.load_library()
-lib.pt_diag_stamps.argtypes = [C.c_void_p, C.c_void_p]
+lib = ptmi.load_library(diag=True)
 assert lib.pt_diag_stamps(r.handle, out) == 0
 t = np.array(out, dtype=np.uint64).reshape(2, 16, 8).astype(np.int64)
 names = ["MFMA k0", "load A", "MFMA k1", "load B"] if NPH == 4 else ["MFMA x16", "load"]

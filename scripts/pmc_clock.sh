@@ -7,7 +7,7 @@ set -e
 ROOT=$GRAFT_REPO_ROOT; TAG=$1; shift
 OUT=$ROOT/gpurun_out/$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-export PTMI_LIBRARY=$ROOT/ipu_path_trace_amd/libptmi_diag.so
+export QB_DIAG=1   # quick_bench.py loads libptmi_diag.so
 for v in "$@"; do
   name=${v%%=*}; envs=${v#*=}
   unset PTMI_NIF_DIAG PTMI_NIF_VARIANT PTMI_SERIAL PTMI_NIF_KERNEL PTMI_GEMM_DIAG

@@ -3,7 +3,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ipu_path_trace_amd import ptmi, nif_assets as A
 W,H=1104,1000
 spps = [int(x) for x in sys.argv[1:]] or [32, 300]
-r=ptmi.Renderer(W,H,max_path_length=8)
+DIAG = os.environ.get('QB_DIAG') == '1'   # the profiling build (libptmi_diag.so): the PTMI_* A/B switches only exist there
+r=ptmi.Renderer(W,H,max_path_length=8,diag=DIAG)
 L=A.synthetic_nif(hidden=int(os.environ.get('AB_HIDDEN','320')),layer_count=int(os.environ.get('AB_LAYERS','6')))
 r.init_nif_weights(L,12,A.URBAN_ALLEY_META['max'],A.folded_mean())
 for spp in spps:

@@ -71,6 +71,24 @@ def test_product_package_never_imports_the_oracle():
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(d, f)
 
 
+def test_product_library_carries_no_test_hook(ptmi_lib):
+    """Nothing in the environment can change what libptmi.so does: no PTMI_* string (the A/B switches, fault injection and
+    tuning knobs live only in libptmi_diag.so, -DPTMI_DIAG_BUILD) and no pt_diag_* symbol; the package never reads an
+    environment variable to pick a library; bench.py loads the product library only."""
+    lib = ptmi_lib.load_library()
+    blob = open(lib._name, "rb").read()
+    assert b"PTMI_" not in blob
+    assert not hasattr(lib, "pt_diag_inject_fault") and not hasattr(lib, "pt_diag_stamps")
+    import subprocess
+    syms = subprocess.run(["nm", "-D", "--undefined-only", lib._name], capture_output=True, text=True).stdout
+    assert "getenv" not in syms, "libptmi.so must not read the environment"
+    for rel in ("ipu_path_trace_amd/build.py", "ipu_path_trace_amd/ptmi.py", "bench.py"):
+        src = open(os.path.join(ROOT, rel)).read()
+        assert "PTMI_LIBRARY" not in src and "diag=True" not in src, rel
+    diag = ptmi_lib.load_library(diag=True)
+    assert hasattr(diag, "pt_diag_inject_fault") and hasattr(diag, "pt_diag_stamps")
+
+
 def test_comm_entry_points_reject_bad_arguments_without_a_gpu(ptmi_lib):
     """librccl is linked into libptmi.so (the north_star's RCCL gather lives behind the C-ABI); argument checks need
     no device."""

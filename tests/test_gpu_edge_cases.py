@@ -190,25 +190,24 @@ def test_rccl_gather_of_hdr_tiles_single_rank(ptmi_lib):
 
 
 def test_failed_path_trace_drains_and_the_handle_stays_usable(oracle, ptmi_lib):
-    """A launch failure in the MIDDLE of the batch loop (injected: PTMI_FAULT_INJECT) must come back as an error with all
+    """A launch failure in the MIDDLE of the batch loop (injected through pt_diag_inject_fault, which exists only in the test
+    build libptmi_diag.so -- same sources, -DPTMI_DIAG_BUILD; the product library has no hook) must come back as an error with all
     three streams drained -- the earlier batches are already queued when it happens -- must not advance the sample
     sequence, and must leave the handle usable: after a fresh setup the same step gives the oracle's result."""
-    import os
     O = oracle
     W = H = 48
     L, mx, mean = _nif()
-    r = ptmi_lib.Renderer(W, H, max_path_length=6, iterations_per_batch=2)      # 6 spp = 3 batches
+    r = ptmi_lib.Renderer(W, H, max_path_length=6, iterations_per_batch=2, diag=True)      # 6 spp = 3 batches
     r.init_nif_weights(L, 12, mx, mean)
     r.init_render_settings(samples_per_step=6)
     rec = ptmi_lib.worklist(W, H)
     r.setup(rec)
-    os.environ["PTMI_FAULT_INJECT"] = "nif_launch:1"
-    try:
-        with pytest.raises(ptmi_lib.PtError) as e:
-            r.path_trace()
-        assert e.value.code == -3 and "injected fault" in str(e.value)
-    finally:
-        del os.environ["PTMI_FAULT_INJECT"]
+    diag = ptmi_lib.load_library(diag=True)
+    assert diag.pt_diag_inject_fault(r.handle, 1) == 0
+    with pytest.raises(ptmi_lib.PtError) as e:
+        r.path_trace()
+    assert e.value.code == -3 and "injected fault" in str(e.value)
+    assert diag.pt_diag_inject_fault(r.handle, -1) == 0
     r.synchronize()                                                             # nothing left running
     rec = ptmi_lib.worklist(W, H)
     r.setup(rec)                                                                # accumulators are undefined after a failure
