@@ -9,6 +9,11 @@ N > 1: one process per GPU (torch.distributed, backend nccl = RCCL).  The image 
 (ipu_path_trace_amd/partition.py), every rank traces its tiles with no data-path collective, and the
 HDR tiles are gathered to rank 0 once per save interval (here: once, after the last timed step).
 Total work is fixed as N grows -> "scaling": "strong".
+
+`python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset) starts its own N ranks: the parent, before
+it touches the GPU in any way, runs `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+127.0.0.1 ... bench.py <same arguments>` as a CHILD process, relays its output (rank 0's JSON line) and exits with its
+code -- the reference's `--ipus N` is one command too (src/main.cpp:17-19, src/PathTracerApp.cpp:205-252).
 """
 import argparse
 import json
@@ -87,6 +92,26 @@ def cpu_baseline(width, height, depth, layers, meta, mean, target_seconds=12.0):
             "(%.1f s of CPU work)" % (n, width, height, spp, depth, dt)}
 
 
+def spawn_ranks(n):
+    """Launch this script as n ranks under torch.distributed.run, as a child process; relay stdout and the exit code.
+    Nothing in this (parent) process has initialised the GPU: no exec of a GPU process, only a child."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    for line in child.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return child.wait()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -105,6 +130,10 @@ def main():
     ap.add_argument("--enable-load-balancing", action="store_true",
                     help="re-deal image tiles between ranks by measured path length at every save interval")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -155,6 +184,13 @@ def main():
     # the driver's launcher has set up anyway.  Should the communicator fail to come up on some rank, every rank falls
     # back to torch.distributed's gather of the same device buffers and the bench line says so.
     product_gather = False
+    COMM_TIMEOUT_MS = 60000   # a rank whose peers never arrive gives up after this long and everyone takes the fallback
+
+    def everyone(ok):
+        flag = torch.tensor([int(ok)], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item())
+
     if world > 1 and not rehearsal:
         ok, why, uid = 1, "", None
         if rank == 0:
@@ -168,12 +204,11 @@ def main():
             ok = 0
         else:
             try:
-                r.comm_init_rank(ids[0], rank, world)
+                r.comm_set_timeout(COMM_TIMEOUT_MS)
+                r.comm_init_rank(ids[0], rank, world)   # non-blocking set-up polled against the deadline: never a hang
             except Exception as e:   # noqa: BLE001 -- any failure means "use the fallback", on every rank
                 ok, why = 0, str(e)
-        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        product_gather = bool(flag.item())
+        product_gather = everyone(ok)
         gathered["via"] = ("pt_gather_hdr (RCCL inside libptmi.so)" if product_gather
                            else "torch.distributed gather (pt_comm_init_rank failed: %s)" % (why or "on another rank"))
     elif world > 1:
@@ -191,6 +226,9 @@ def main():
         if product_gather:
             gathered["tiles"] = r.gather_hdr(slot)                      # export + RCCL gather + copy to the host
             return
+        fallback_gather(n_items)
+
+    def fallback_gather(n_items):
         r.export_hdr_device(hdr.data_ptr(), n_items)
         if rehearsal:
             torch.cuda.synchronize()
@@ -228,10 +266,22 @@ def main():
 
     for _ in range(args.warmup):
         r.path_trace()
-    if world > 1 and args.warmup:
+    if world > 1 and (args.warmup or product_gather):
         # untimed: the first gather sets up RCCL's point-to-point channels (lazily, on first use); the timed hand-off
-        # must measure the transfer, not the connection set-up
-        gather_hdr(work.size)
+        # must measure the transfer, not the connection set-up.  It is also the proof that the product gather works on
+        # this node: if it fails or times out on ANY rank, every rank switches to torch.distributed's gather.
+        if product_gather:
+            ok, why = 1, ""
+            try:
+                gather_hdr(work.size)
+            except ptmi.PtError as e:
+                ok, why = 0, str(e)
+            if not everyone(ok):
+                product_gather = False
+                gathered["via"] = "torch.distributed gather (pt_gather_hdr failed in the warm-up: %s)" % (why or "on another rank")
+                fallback_gather(work.size)
+        else:
+            gather_hdr(work.size)
     if args.warmup and args.save_interval > 0:
         r.setup(work)                                                         # intervals count timed steps only
     agg = {"escaped": 0, "segments": 0, "paths": 0, "nif_ms": 0.0, "trace_ms": 0.0, "acc_ms": 0.0, "nif_launches": 0}

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PTMI_ABI_VERSION 2
+#define PTMI_ABI_VERSION 3
 
 typedef struct pt_context* pt_handle;
 
@@ -171,13 +171,27 @@ int pt_get_stats(pt_handle h, pt_stats* stats);
  * Communicators: one rank per handle.  One process per GPU: rank 0 calls pt_comm_get_unique_id, hands the
  * PT_COMM_ID_BYTES bytes to the other processes by any means (MPI, torch.distributed, a file), everyone calls
  * pt_comm_init_rank.  One process driving several GPUs (ipu_trace --ipus N): pt_comm_init_all on the list of
- * handles; pt_gather_hdr is then called from one thread per handle.  pt_destroy releases the communicator. */
+ * handles; pt_gather_hdr is then called from one thread per handle.  pt_destroy releases the communicator.
+ *
+ * No communicator call blocks for ever (the reference's Poplar engine has no such failure mode: its IPUs are one
+ * device, PathTracerApp.cpp:205-252).  Communicators are non-blocking RCCL communicators; set-up and every exchange
+ * are polled against a deadline (pt_comm_set_timeout, default 120000 ms).  slot_items is checked for agreement between
+ * the ranks once per communicator and slot size (PT_ERR_INVALID_ARGUMENT on every rank if it differs).  If a peer never
+ * joins an exchange (it failed a local check and returned early, crashed, or was never started), if RCCL reports an
+ * asynchronous error, or if another thread calls pt_comm_abort(h), the waiting rank aborts its communicator
+ * (ncclCommAbort), drains its stream and returns PT_ERR_COMM; the handle then has no communicator and pt_gather_hdr
+ * keeps returning PT_ERR_COMM until pt_comm_init_rank / pt_comm_init_all gives it a new one.  CONTRACT for callers
+ * that drive several ranks: when one rank's call fails, abort the others (pt_comm_abort -- the only pt_* function
+ * that may be called from another thread while a call on the same handle is in progress) or let them time out.
+ * Multi-rank exchanges have not been run on hardware yet (no multi-GPU box was available): DESIGN.md section 6. */
 enum { PT_HDR_ACCUMULATORS = 0, PT_HDR_FILM = 1 };
 #define PT_COMM_ID_BYTES 128
 int pt_comm_get_unique_id(void* id_out);
 int pt_comm_init_rank(pt_handle h, const void* id, int rank, int world);
 int pt_comm_init_all(pt_handle* handles, int n);
 int pt_comm_info(pt_handle h, int* rank, int* world);
+int pt_comm_set_timeout(pt_handle h, uint32_t milliseconds);
+int pt_comm_abort(pt_handle h);
 int pt_film_accumulate(pt_handle h);
 int pt_gather_hdr(pt_handle h, int32_t source, size_t slot_items, float* root_host_bgr);
 int pt_export_hdr_device(pt_handle h, void* device_bgr, size_t n);

@@ -27,6 +27,10 @@ public:
       pt_log::error_(msg);
       throw std::logic_error(msg);
     }
+    if (failure) {   // (cannot happen through waitForCompletion, which collects it; never let a stale failure reach a later job)
+      pt_log::error_("AsyncTask: an earlier job's failure was never collected; dropping it.");
+      failure = nullptr;
+    }
     task = std::move(f);
     busy.store(true);
     worker = std::thread([this] {

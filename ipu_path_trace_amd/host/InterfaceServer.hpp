@@ -175,6 +175,10 @@ private:
         handle(pending.substr(0, nl));
         pending.erase(0, nl + 1);
       }
+      if (pending.size() > kMaxLineBytes) {   // a client that never sends a newline must not grow this buffer for ever
+        pt_log::warn_("User interface: dropping {} bytes without a line end", pending.size());
+        pending.clear();
+      }
     }
     if (!stopServer) {
       std::lock_guard<std::mutex> lock(stateMutex);
@@ -184,19 +188,39 @@ private:
     pt_log::info_("User interface server Tx/Rx loop exited.");
   }
 
+  // A value the device would refuse (pt_set_render_settings: 1 <= samples <= 65535, 0 < fov < pi) or that did not
+  // parse is rejected HERE with a warning and the old state kept: a typo from the client must not abort the render.
+  // (The reference's UI sends slider values, which cannot be out of range; a text client can send anything.)
   void handle(const std::string& line) {
     std::istringstream is(line);
     std::string name;
     is >> name;
+    auto number = [&](float lo, float hi, bool openInterval, float& out) {
+      float v = 0.f;
+      std::string rest;
+      const bool parsed = static_cast<bool>(is >> v) && std::isfinite(v) && !(is >> rest);
+      const bool inRange = openInterval ? (v > lo && v < hi) : (v >= lo && v <= hi);
+      if (!parsed || !inRange) {
+        pt_log::warn_("User interface: '{}' rejected (want a number in {}{}, {}{}); state unchanged", line, openInterval ? "(" : "[", lo, hi,
+                      openInterval ? ")" : "]");
+        return false;
+      }
+      out = v;
+      return true;
+    };
     std::lock_guard<std::mutex> lock(stateMutex);
-    if (name == "env_rotation") { is >> state.envRotationDegrees; stateUpdated = true; }
+    float v = 0.f;
+    if (name == "env_rotation") { if (number(-36000.f, 36000.f, false, v)) { state.envRotationDegrees = v; stateUpdated = true; } }
     else if (name == "detach") { state.detach = true; stateUpdated = true; }
     else if (name == "stop") { state.stop = true; stateUpdated = true; }
-    else if (name == "exposure") { is >> state.exposure; }        // host-side only: no restart (:124-129)
-    else if (name == "gamma") { is >> state.gamma; }
-    else if (name == "fov") { float deg = 90.f; is >> deg; state.fov = deg * (float)(M_PI / 180.f); stateUpdated = true; }
+    else if (name == "exposure") { if (number(-64.f, 64.f, false, v)) state.exposure = v; }        // host-side only: no restart (:124-129)
+    else if (name == "gamma") { if (number(0.f, 64.f, true, v)) state.gamma = v; }
+    else if (name == "fov") { if (number(0.f, 180.f, true, v)) { state.fov = v * (float)(M_PI / 180.f); stateUpdated = true; } }
     else if (name == "load_nif") { std::getline(is >> std::ws, state.newNif); stateUpdated = true; }
-    else if (name == "interactive_samples") { is >> state.interactiveSamples; stateUpdated = true; }
+    else if (name == "interactive_samples") {
+      if (number(1.f, 65535.f, false, v) && v == std::floor(v)) { state.interactiveSamples = (std::uint32_t)v; stateUpdated = true; }
+      else if (v != std::floor(v)) pt_log::warn_("User interface: '{}' rejected (want a whole number); state unchanged", line);
+    }
     else if (!name.empty()) pt_log::warn_("User interface: unknown command '{}'", name);
   }
 
@@ -222,6 +246,7 @@ private:
     return sendAll(l.data(), l.size()) && sendAll(data, bytes);
   }
 
+  static constexpr std::size_t kMaxLineBytes = 4096;
   int port;
   int listenFd = -1, clientFd = -1;
   std::unique_ptr<std::thread> thread;

@@ -162,18 +162,30 @@ void PathTracerApp::initialiseState(std::uint32_t imageWidth, std::uint32_t imag
   traceState->work.getWork().active() = traceState->work.getWork().inactive();
 }
 
+// One call per device, each from its own thread (the devices work at the same time, as the IPUs of one Poplar engine do:
+// PathTracerApp.cpp:205-252).  The FIRST failure is the one reported; the thread that fails asks every other device
+// to abort its communicator (pt_comm_abort), so a sibling waiting inside the HDR gather for the failed rank returns at
+// once with PT_ERR_COMM instead of at its deadline -- the join below can therefore never wait for ever.
 template <class F>
 void PathTracerApp::onEveryDevice(const char* what, F&& call) {
   std::vector<std::string> errors(devices.size());
+  std::atomic<int> firstFailed{-1};
   if (devices.size() == 1) {
-    if (call(0)) errors[0] = pt_last_error(devices[0]);
+    if (call(0)) { errors[0] = pt_last_error(devices[0]); firstFailed = 0; }
   } else {
     std::vector<std::thread> runners;
     for (std::size_t d = 0; d < devices.size(); ++d)
-      runners.emplace_back([&, d]() { if (call(d)) errors[d] = pt_last_error(devices[d]); });
+      runners.emplace_back([&, d]() {
+        if (!call(d)) return;
+        errors[d] = pt_last_error(devices[d]);
+        int none = -1;
+        if (firstFailed.compare_exchange_strong(none, (int)d))
+          for (std::size_t o = 0; o < devices.size(); ++o) if (o != d) pt_comm_abort(devices[o]);
+      });
     for (auto& t : runners) t.join();
   }
-  for (auto& e : errors) if (!e.empty()) throw std::runtime_error(std::string(what) + " failed: " + e);
+  const int f = firstFailed.load();
+  if (f >= 0) throw std::runtime_error(std::string(what) + " failed on device " + std::to_string(f) + ": " + errors[(std::size_t)f]);
 }
 
 void PathTracerApp::execute() {
@@ -185,7 +197,7 @@ void PathTracerApp::execute() {
   const float degrees = args.f32("env-map-rotation");
   const float radians = (degrees / 360.f) * (float)(2.0 * M_PI);          // PathTracerApp.cpp:584
 
-  auto startTime = std::chrono::steady_clock::now();
+  renderStartTime = std::chrono::steady_clock::now();
 
   // programs init_nif_weights and init_render_settings (PathTracerApp.cpp:612-614)
   for (std::size_t d = 0; d < devices.size(); ++d) {
@@ -210,7 +222,7 @@ void PathTracerApp::execute() {
   else executeResidentFilm(steps);
 
   auto endTime = std::chrono::steady_clock::now();
-  const auto elapsedSecs = std::chrono::duration<double>(endTime - startTime).count();
+  const auto elapsedSecs = std::chrono::duration<double>(endTime - renderStartTime).count();
   pt_log::info_("Render finished: {} seconds", elapsedSecs);
   const std::size_t pixelsPerFrame = (std::size_t)imageWidth * imageHeight;
   finalSamplesPerSec = (pixelsPerFrame / elapsedSecs) * samplesPerPixel;   // PathTracerApp.cpp:786-789
@@ -256,16 +268,18 @@ void PathTracerApp::executeResidentFilm(std::uint32_t steps) {
   const float configExposure = args.f32("exposure"), configGamma = args.f32("gamma");
   const auto fileName = args.str("outfile");
   const auto saveInterval = args.u32("save-interval");
-  AsyncTask hostProcessing;
 
   // program setup, once: the worklist (pixel coordinates, zero accumulators) goes to the devices and stays there
   auto& work = traceState->work.getWork().active();
   const std::size_t itemsPerDevice = work.size() / devices.size();
+  std::vector<float> tiles(work.size() * 3);   // rank 0 receives [device][itemsPerDevice][3] BGR film sums
+  RecordList filmRecords;                      // the gathered film as records AccumulatedImage::accumulate takes
+  // Declared AFTER everything its job reads (tiles, filmRecords): if the step loop throws, unwinding destroys -- and so
+  // joins -- the task first, while those buffers are still alive.
+  AsyncTask hostProcessing;
   onEveryDevice("setup", [&](std::size_t d) {
     return pt_setup(devices[d], reinterpret_cast<const pt_trace_record*>(work.data() + d * itemsPerDevice), itemsPerDevice);
   });
-  std::vector<float> tiles(work.size() * 3);   // rank 0 receives [device][itemsPerDevice][3] BGR film sums
-  RecordList filmRecords;                      // the gathered film as records AccumulatedImage::accumulate takes
 
   for (auto step = 1u; step <= steps; ++step) {
     auto loopStartTime = std::chrono::steady_clock::now();
@@ -317,7 +331,6 @@ void PathTracerApp::executeHostFilm(std::uint32_t steps) {
   const auto saveInterval = args.u32("save-interval");
   const auto seed = args.u64("seed");
   const float antiAliasingScale = args.f32("aa-noise-scale");
-  AsyncTask hostProcessing;
   std::atomic<std::size_t> totalRays{0};   // written by the host task, read by the step log
   const std::size_t itemsPerDevice = traceState->work.getWork().active().size() / devices.size();
 
@@ -335,6 +348,9 @@ void PathTracerApp::executeHostFilm(std::uint32_t steps) {
     uiServer->start();
     uiServer->initialiseVideoStream(imageWidth, imageHeight);
   }
+  // Declared AFTER the server, the state and the counter its job uses: if anything in the loop throws, unwinding joins
+  // the task (its destructor) before the InterfaceServer it talks to is destroyed.
+  AsyncTask hostProcessing;
   constexpr std::size_t sampleCountReversionStep = 5;
   std::uint32_t lastStep = 0;   // steps accumulated into the current film
   auto sendRenderSettings = [&]() {   // program init_render_settings (PathTracerApp.cpp:678-686)
@@ -361,16 +377,21 @@ void PathTracerApp::executeHostFilm(std::uint32_t steps) {
         hostProcessing.waitForCompletion();
         uiServer.reset();
       } else if (status == InterfaceServer::Status::Restart) {
+        renderStartTime = loopStartTime;   // the final Samples/sec counts from the restart (:669)
         step = 1;
         samplesPerIpuStep = state.interactiveSamples;
       }
-    } else if (uiServer && step == sampleCountReversionStep) {
-      // No UI input for a few steps so revert to performant number of samples:
-      samplesPerIpuStep = args.u32("samples-per-step");
-      pt_log::debug_("Interaction stopped reverting samples per step to: {}", samplesPerIpuStep);
+    } else {
+      // (no `uiServer &&` here, as in the reference: a client that restarts the render and then detaches or closes must
+      // not leave the device on the interactive sample count for the rest of the run)
+      if (step == sampleCountReversionStep) {
+        // No UI input for a few steps so revert to performant number of samples:
+        samplesPerIpuStep = args.u32("samples-per-step");
+        pt_log::debug_("Interaction stopped reverting samples per step to: {}", samplesPerIpuStep);
+      }
     }
-    // Render settings can only be updated on these steps (:678-686):
-    if (uiServer && (step == 1 || step == sampleCountReversionStep)) sendRenderSettings();
+    // Render settings can only be updated on these steps (:678-686), server or no server:
+    if (step == 1 || step == sampleCountReversionStep) sendRenderSettings();
 
     // setup -> path_trace -> read_results on every device (PathTracerApp.cpp:692-694).  The worklist is
     // cut into equal contiguous slices, one per device, as tiles are cut over IPUs.
@@ -384,6 +405,7 @@ void PathTracerApp::executeHostFilm(std::uint32_t steps) {
     pt_log::debug_("Path-Trace ms: {}", stats[0].path_trace_ms);
     pt_log::debug_("NIF ms: {}", stats[0].nif_ms);
     pt_log::debug_("Total ms per step: {}", stats[0].total_ms);
+    pt_log::debug_("Step {} took {} samples per pixel", step, stats[0].paths / itemsPerDevice);
 
     const auto deviceDone = std::chrono::steady_clock::now();
     hostProcessing.waitForCompletion();    // join the previous async task before swapping (:703-708)

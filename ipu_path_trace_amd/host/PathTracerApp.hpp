@@ -65,6 +65,7 @@ private:
   std::unique_ptr<PathTracerState> traceState;
   std::unique_ptr<PathTracerState> defunctTraceState;   // keeps defunct data alive while the async host task finishes on it
   double finalSamplesPerSec = 0.0;
+  std::chrono::steady_clock::time_point renderStartTime;   // reset when the UI restarts the render (PathTracerApp.cpp:669)
 };
 
 std::size_t roundSamplesPerPixel(std::size_t samplesPerPixel, std::size_t samplesPerIpuStep);

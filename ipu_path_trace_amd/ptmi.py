@@ -22,7 +22,8 @@ DTYPE_F16, DTYPE_F32 = 0, 1
 EXPORTS = ["pt_abi_version", "pt_create", "pt_destroy", "pt_last_error", "pt_upload_nif", "pt_set_constant_env",
            "pt_set_render_settings", "pt_setup", "pt_path_trace", "pt_read_results", "pt_get_stats",
            "pt_export_hdr_device", "pt_clear_accumulators", "pt_synchronize", "pt_nif_infer", "pt_trace_paths",
-           "pt_comm_get_unique_id", "pt_comm_init_rank", "pt_comm_init_all", "pt_comm_info", "pt_gather_hdr", "pt_film_accumulate"]
+           "pt_comm_get_unique_id", "pt_comm_init_rank", "pt_comm_init_all", "pt_comm_info", "pt_comm_set_timeout", "pt_comm_abort",
+           "pt_gather_hdr", "pt_film_accumulate"]
 COMM_ID_BYTES = 128
 HDR_ACCUMULATORS, HDR_FILM = 0, 1
 
@@ -95,6 +96,8 @@ def load_library(diag=False):
     L.pt_comm_init_rank.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     L.pt_comm_init_all.argtypes = [C.POINTER(C.c_void_p), C.c_int]
     L.pt_comm_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.pt_comm_set_timeout.argtypes = [C.c_void_p, C.c_uint32]
+    L.pt_comm_abort.argtypes = [C.c_void_p]
     L.pt_gather_hdr.argtypes = [C.c_void_p, C.c_int32, C.c_size_t, C.c_void_p]
     L.pt_film_accumulate.argtypes = [C.c_void_p]
     L.pt_clear_accumulators.argtypes = [C.c_void_p]
@@ -221,6 +224,14 @@ class Renderer:
         rank, world = C.c_int(), C.c_int()
         self._check(self._lib.pt_comm_info(self.handle, C.byref(rank), C.byref(world)))
         return rank.value, world.value
+
+    def comm_set_timeout(self, milliseconds):
+        """Deadline of every communicator operation of this handle (set-up, slot agreement, gather)."""
+        self._check(self._lib.pt_comm_set_timeout(self.handle, int(milliseconds)))
+
+    def comm_abort(self):
+        """Ask the handle to abort its communicator; callable from another thread while a gather is waiting."""
+        self._check(self._lib.pt_comm_abort(self.handle))
 
     def film_accumulate(self):
         """AccumulatedImage::accumulate + clearInactiveAccumulators on the device (the film stays resident)."""

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol(ptmi_lib):
     for n in names:
         assert hasattr(lib, n), "libptmi.so does not export %s" % n
     assert sorted(ptmi_lib.EXPORTS) == names
-    assert lib.pt_abi_version() == 2   # 2: communicator + pt_gather_hdr, PT_DTYPE_F32
+    assert lib.pt_abi_version() == 3   # 2: communicator + pt_gather_hdr, PT_DTYPE_F32; 3: communicator deadlines + pt_comm_abort, pt_tile_costs
 
 
 def test_struct_layouts_match_header(ptmi_lib):
@@ -99,6 +99,7 @@ def test_comm_entry_points_reject_bad_arguments_without_a_gpu(ptmi_lib):
     assert lib.pt_comm_init_rank(None, None, 0, 1) == -1
     assert lib.pt_comm_init_all(None, 0) == -1
     assert lib.pt_gather_hdr(None, 0, 10, None) == -1
+    assert lib.pt_comm_set_timeout(None, 1000) == -1 and lib.pt_comm_abort(None) == -1
     assert lib.pt_film_accumulate(None) == -1
     import subprocess
     deps = subprocess.run(["readelf", "-d", lib._name], capture_output=True, text=True).stdout

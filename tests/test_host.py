@@ -390,6 +390,109 @@ def test_interactive_restart_and_nif_hot_reload_over_the_ui_port(host, tmp_path)
 
 
 @pytest.mark.gpu
+def test_restart_then_detach_still_reverts_to_the_full_sample_count(host, tmp_path):
+    """PathTracerApp.cpp:656-686: the reversion to --samples-per-step at step 5 and the init_render_settings at steps 1
+    and 5 do not depend on a UI server being attached.  A client that changes a setting (restart: the device goes to
+    --interactive-samples) and then closes its socket before step 5 must not leave the render on the interactive
+    sample count: steps >= 5 take the full count again, and the final image is written."""
+    import re
+    import socket
+    import time
+    exe = os.path.join(HOST, "ipu_trace")
+    assets = tmp_path / "assets.extra"
+    assets.mkdir()
+    nif_assets.write_metadata(str(assets / "nif_metadata.txt"))
+    nif_assets.write_ptnif(str(assets / "converted.ptnif"), nif_assets.synthetic_nif(), 12)
+    W, H, full, inter, steps = 1104, 1000, 96, 48, 9           # big enough that a step takes tens of milliseconds
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = tmp_path / "detach.png"
+    proc = subprocess.Popen([exe, "--assets", str(assets), "-w", str(W), "-h", str(H), "-s", str(full * steps), "--samples-per-step", str(full),
+                             "--interactive-samples", str(inter), "--max-path-length", "5", "-o", str(out), "--save-interval", "100",
+                             "--ui-port", str(port), "--log-level", "debug"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    conn = None
+    for _ in range(600):
+        try:
+            conn = socket.create_connection(("127.0.0.1", port), timeout=1.0)
+            break
+        except OSError:
+            time.sleep(0.1)
+    assert conn is not None, "ui server never came up"
+    f = conn.makefile("rb")
+
+    def next_progress():
+        while True:
+            line = f.readline()
+            assert line, "server closed the connection"
+            t = line.decode().split()
+            if t[0] == "progress":
+                return float(t[1])
+            if t[0] == "render_preview":
+                f.read(int(t[3]))
+
+    first = next_progress()
+    conn.sendall(b"env_rotation 25\n")                       # restart at step 1 with the interactive sample count
+    p = next_progress()
+    while p > first + 1e-6 or p > 1.5 / steps:                 # wait for step 1 of the RESTARTED render ...
+        first, p = min(first, p), next_progress()
+    conn.close()                                               # ... and leave at once: detached around step 2
+    log, _ = proc.communicate(timeout=180)
+    assert proc.returncode == 0, log[-3000:]
+    assert "Remote UI disconnected." in log
+    tail = log[log.rindex("Completed render step 1/%d" % steps):]          # the restarted render
+    assert "Remote UI disconnected." in tail, "the client detached before the restart was processed: scenario not reached"
+    took = {int(a): int(b) for a, b in re.findall(r"Step (\d+) took (\d+) samples per pixel", tail)}
+    gone = tail.index("Remote UI disconnected.")
+    revert = tail.index("Interaction stopped reverting samples per step to: %d" % full)
+    assert gone < revert, "the detach came after step 5: scenario not reached (steps too fast)"
+    assert all(took[k] == full for k in range(5, steps + 1)), took       # full count again once the interaction is over
+    assert took[2] == inter or took[3] == inter, took                     # and the interactive count before that
+    assert "Saved images at step %d" % steps in log and os.path.getsize(out) > 500
+
+
+@pytest.mark.gpu
+def test_ui_client_cannot_abort_the_render_with_a_bad_value(host, tmp_path):
+    """A value pt_set_render_settings would refuse (or that does not parse) is rejected by the server with a warning and
+    the state kept; the render carries on and ends normally (a typo from the client aborted the render)."""
+    import socket
+    import time
+    exe = os.path.join(HOST, "ipu_trace")
+    assets = tmp_path / "assets.extra"
+    assets.mkdir()
+    nif_assets.write_metadata(str(assets / "nif_metadata.txt"))
+    nif_assets.write_ptnif(str(assets / "converted.ptnif"), nif_assets.synthetic_nif(), 12)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = tmp_path / "bad.png"
+    proc = subprocess.Popen([exe, "--assets", str(assets), "-w", "64", "-h", "48", "-s", "100000", "--samples-per-step", "10",
+                             "--max-path-length", "4", "-o", str(out), "--ui-port", str(port)],
+                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    conn = None
+    for _ in range(600):
+        try:
+            conn = socket.create_connection(("127.0.0.1", port), timeout=1.0)
+            break
+        except OSError:
+            time.sleep(0.1)
+    assert conn is not None
+    conn.sendall(b"interactive_samples 0\nfov 0\nfov 200\ninteractive_samples 70000\ninteractive_samples abc\nfov\ngamma 0\n"
+                 b"env_rotation nan\ninteractive_samples 2.5\n" + b"x" * 10000 + b"\n")
+    time.sleep(1.0)
+    assert proc.poll() is None, "the render died on a bad value"
+    conn.sendall(b"fov 60\n")                                   # a good value still restarts the render
+    time.sleep(0.5)
+    conn.sendall(b"stop\n")
+    log, _ = proc.communicate(timeout=60)
+    assert proc.returncode == 0, log[-3000:]
+    assert log.count("rejected") >= 9 and "Rendering stopped by remote UI" in log
+    assert log.count("Completed render step 1/10000") >= 2       # first run + the restart for fov 60
+
+
+@pytest.mark.gpu
 def test_cli_on_the_reference_assets_directory(host, tmp_path):
     """`--assets` pointed at the reference's own assets.extra (only nif_metadata.txt is shipped: the trained weights are
     absent, so `--synthetic-nif` supplies seeded stand-ins of the architecture the metadata names: 6 x 320, embedding 12)."""
