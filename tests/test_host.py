@@ -437,7 +437,9 @@ def test_restart_then_detach_still_reverts_to_the_full_sample_count(host, tmp_pa
     p = next_progress()
     while p > first + 1e-6 or p > 1.5 / steps:                 # wait for step 1 of the RESTARTED render ...
         first, p = min(first, p), next_progress()
-    conn.close()                                               # ... and leave at once: detached around step 2
+    conn.shutdown(socket.SHUT_RDWR)                            # ... and leave at once: detached around step 2
+    f.close()                                                  # (a makefile() object keeps the descriptor open)
+    conn.close()
     log, _ = proc.communicate(timeout=180)
     assert proc.returncode == 0, log[-3000:]
     assert "Remote UI disconnected." in log
@@ -479,6 +481,16 @@ def test_ui_client_cannot_abort_the_render_with_a_bad_value(host, tmp_path):
         except OSError:
             time.sleep(0.1)
     assert conn is not None
+    import threading
+
+    def drain():                                                 # a client that stops reading would block the server's sends
+        try:
+            while conn.recv(65536):
+                pass
+        except OSError:
+            pass
+
+    threading.Thread(target=drain, daemon=True).start()
     conn.sendall(b"interactive_samples 0\nfov 0\nfov 200\ninteractive_samples 70000\ninteractive_samples abc\nfov\ngamma 0\n"
                  b"env_rotation nan\ninteractive_samples 2.5\n" + b"x" * 10000 + b"\n")
     time.sleep(1.0)
