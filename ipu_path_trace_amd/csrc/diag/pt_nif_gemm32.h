@@ -1,53 +1,13 @@
-// pt_nif_gemm.h -- wide NIFs (hidden 512 / 1024, BASELINE config C5) layer by layer.
-//
-// A 1024-wide activation vector fits neither a wave's registers nor, for more than 64 samples, a CU's LDS, and a
-// 64-sample tile re-streams 2 MiB of weights per layer for 134 MFLOP (64 FLOP per weight byte: the fused
-// nif_wide_kernel is bound by that stream at ~240 TFLOP/s).  At this width a layer is a large enough GEMM
-// (2 K N = 2.1 MFLOP against 4 KiB of activation traffic per sample) to run on its own: the queue is cut into
-// chunks of a few thousand 32-sample tiles whose activations ping-pong between two HBM buffers, and each layer
-// is one launch of nifg_layer_kernel over the chunk.
-//
-// Both operands are stored as ready-made MFMA fragments, 1 KiB pieces of [lane][8 fp16]:
-//   weights      piece (j, s)  = A operand of output tile j (32 features), k-step s    (pack_nif, ptmi.hip)
-//   activations  piece (t, s)  = B operand of sample tile t (32 samples), k-step s
-// and an accumulator tile, rounded to fp16 with bias and ReLU applied, IS the pair of pieces (t, 2j), (t, 2j + 1)
-// of the next layer (the k permutation is folded into the weight packing, as in pt_nif.h), so a layer's epilogue
-// writes whole pieces and the next layer's loader copies pieces global -> LDS by DMA with no transposition.
-// Rounding points are those of NifModel.cpp:295-326, identical to the fused kernels.
+// pt_nif_gemm32.h -- PROFILING BUILD ONLY: the round-2 layer-by-layer kernels on v_mfma_f32_32x32x16_f16 (32-sample
+// pieces of 16 inputs), kept as the A/B baseline of the 16x16x32 kernels in ../pt_nif_gemm.h (PTMI_GEMM_SHAPE=32 at
+// pt_upload_nif selects them; scripts/ab_c5.py).  Shared declarations (NifGemmParams, ring constants, scan, find_tile)
+// come from ../pt_nif_gemm.h.
 #pragma once
-#include "pt_nif.h"
+#include "pt_nif_gemm.h"
 
 namespace ptd {
 
-struct NifGemmParams {
-  const uint4* wpack;        // all weight pieces
-  const uint4* bpack;        // all bias tiles (64 B each)
-  uint32_t piece_base;       // first piece of this layer
-  uint32_t bias_base;        // first bias tile of this layer
-  uint32_t ks_act, ks_in;    // k-steps taken from activations / from the Fourier-feature pieces
-  uint32_t relu;
-  uint32_t n_ftiles;         // 32-feature output tiles of this layer (multiple of 8)
-  const uint4* act_in;       // [tile][act_stride] pieces
-  const uint4* feat;         // [tile][feat_stride] pieces
-  uint4* act_out;            // [tile][act_stride] pieces
-  uint32_t act_stride, feat_stride;
-  const uint32_t* total_tiles;   // device scalar: 32-sample tiles in the queue
-  uint32_t tile0, chunk_tiles;   // this launch covers queue tiles [tile0, tile0 + chunk_tiles)
-  unsigned long long* stamps;    // profiling build only (DIAG bit 6): phase time stamps of workgroup 0, else nullptr
-};
-
-constexpr int kGemmStages = 4;                  // ring slots
-constexpr int kGemmKps = 2;                     // k-steps per stage
-constexpr int kGemmStageBytes = kGemmKps * 16 * 1024;   // 8 A + 8 B pieces per k-step
-constexpr int kGemmBiasBytes = 4096;            // up to 64 output tiles
-constexpr int kGemmLdsBytes = kGemmBiasBytes + kGemmStages * kGemmStageBytes;
-
-// Tiles of the queue in this chunk (0 if the queue ends before it).
-__device__ __forceinline__ uint32_t chunk_tile_count(const uint32_t* total_tiles, uint32_t tile0, uint32_t chunk_tiles) {
-  const uint32_t total = *total_tiles;
-  if (total <= tile0) return 0u;
-  return (total - tile0 < chunk_tiles) ? total - tile0 : chunk_tiles;
-}
+constexpr int kGemmKps = 2;                     // k-steps (of 16) per stage
 
 // One dense layer over a chunk: D[256 features x 256 samples] per workgroup pass, 8 waves of 128 x 64
 // (4 x 2 accumulator tiles of 32 x 32).  Weights and activations arrive by LDS-DMA into a ring of four stages of
@@ -336,47 +296,6 @@ __global__ __launch_bounds__(512, 2) void nifg_layer_kernel(const NifGemmParams 
       for (int i = lane; i < 128; i += 64) P.stamps[((uint32_t)wave >> 2) * 128u + i] = src[i];
     }
   }
-}
-
-// tile_start[r] = first 32-sample tile of queue region r; tile_start[n_regions] = total.  One workgroup.
-__global__ __launch_bounds__(256) void nifg_scan_kernel(const uint32_t* region_count, uint32_t n_regions, uint32_t* tile_start) {
-  __shared__ uint32_t partial[256];
-  const uint32_t per = (n_regions + 255u) / 256u;
-  uint32_t sum = 0;
-  for (uint32_t i = 0; i < per; ++i) {
-    const uint32_t r = threadIdx.x * per + i;
-    if (r < n_regions) sum += (region_count[r] + 31u) / 32u;
-  }
-  partial[threadIdx.x] = sum;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t run = 0;
-    for (int i = 0; i < 256; ++i) { const uint32_t t = partial[i]; partial[i] = run; run += t; }
-    tile_start[n_regions] = run;
-  }
-  __syncthreads();
-  uint32_t run = partial[threadIdx.x];
-  for (uint32_t i = 0; i < per; ++i) {
-    const uint32_t r = threadIdx.x * per + i;
-    if (r < n_regions) { tile_start[r] = run; run += (region_count[r] + 31u) / 32u; }
-  }
-}
-
-// Region and offset of queue tile wt (binary search over the scan in LDS).
-struct TileRef {
-  uint32_t qbase, local, count;
-};
-__device__ __forceinline__ TileRef find_tile(const uint32_t* ts_lds, uint32_t n_regions, const NifParams& P, uint32_t wt) {
-  uint32_t lo = 0, hi = n_regions;
-  while (hi - lo > 1u) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (ts_lds[mid] <= wt) lo = mid; else hi = mid;
-  }
-  TileRef r;
-  r.local = (wt - ts_lds[lo]) * 32u;
-  r.count = P.region_count[lo];
-  r.qbase = lo * P.region_cap + r.local;
-  return r;
 }
 
 // Fourier features of a chunk as B pieces (NifModel.cpp:185-218): feat[tile][E / 4].  One wave per tile.

@@ -20,6 +20,7 @@
 #include "pt_nif.h"
 #include "pt_nif_gemm.h"
 #ifdef PTMI_DIAG_BUILD
+#include "diag/pt_nif_gemm32.h"
 #include "diag/pt_nif16.h"
 #include "diag/pt_nif_variants.h"
 #endif
@@ -115,6 +116,11 @@ struct pt_context {
   bool nif_valid = false;
   int nif_hidden = 0, nif_emb = 0;   // PADDED hidden width / embedding dimension the kernels are instantiated for
   bool nif_gemm = false;  // layer-by-layer path (pt_nif_gemm.h)
+  bool nif_gemm32 = false;   // profiling build: the round-2 32x32x16 layer kernels (diag/pt_nif_gemm32.h) for the A/B
+  float4* d_head_partial = nullptr;   // fused head: [2 FB][chunk samples] partial sums
+  float4* d_head_in = nullptr;        // head weights of the Fourier-feature inputs [4][E], if the head concatenates them
+  float head_bias[3] = {0, 0, 0};
+  uint32_t head_piece_base = 0;
   bool nif_m16 = false;   // weights packed for nif_kernel_v4 (16x16x32 MFMA) rather than the 32x32x16 kernels
   ptd::NifParams nif{};
   uint4* d_wpack = nullptr;
@@ -397,6 +403,99 @@ int pack_nif(pt_handle h, const std::vector<HostLayer>& L, uint32_t E, std::vect
   return PT_OK;
 }
 
+// Wide networks (pt_nif_gemm.h), v_mfma_f32_16x16x32_f16.  Piece (l, s, f): the A operand of k-step s (32 inputs) and
+// feature tile f (16 outputs) of layer l; lane (r = lane & 15, q = lane >> 4) holds W^T[16 f + r][k(q, 0..7)] with
+//  * activation k-step s:  k = 32 s + (e < 4 ? 4 q + e : 16 + 4 q + (e - 4))          (accumulator-as-operand order)
+//  * input k-step s':      coordinate cd = q & 1, frequency f' = 4 (2 s' + (q >> 1)) + (e & 3);
+//                          k = base + (e < 4 ? 0 : 2E) + cd E + f', or a zero weight where f' >= E (padding slots)
+// Pieces of a layer are ordered [s][f] (the two feature tiles a wave loads per stage are adjacent).  The head is one
+// 16-row tile (rows 0..2), activation k-steps only: its feature inputs, if any, go to `head_in` as plain floats
+// [sin u, sin v, cos u, cos v][E] x (B, G, R, -) for nifg16_finish_kernel.  Bias of a 32-feature group: [q][8]:
+// e < 4 -> feature 32 j + 4 q + e, e >= 4 -> 32 j + 16 + 4 q + (e - 4).
+int pack_nif_g16(pt_handle h, const std::vector<HostLayer>& L, uint32_t E, std::vector<uint16_t>& wpack,
+                 std::vector<uint16_t>& bpack, ptd::NifParams& N, std::vector<float>& head_in, float head_bias[3],
+                 uint32_t& head_piece_base) {
+  const uint32_t n = (uint32_t)L.size();
+  if (n < 2 || n > ptd::kMaxLayers) return fail(h, PT_ERR_UNSUPPORTED_MODEL, "NIF must have 2..16 dense layers");
+  if (E == 0 || E % 4) return fail(h, PT_ERR_UNSUPPORTED_MODEL, "embedding dimension must be a multiple of 4");
+  const uint32_t in_dim = 4 * E, H = L[0].cols;
+  if (L[0].rows != in_dim) return fail(h, PT_ERR_UNSUPPORTED_MODEL, "first layer must take the 4*embedding Fourier features");
+  if (H % 256) return fail(h, PT_ERR_UNSUPPORTED_MODEL, "layer-by-layer NIF path needs a hidden width that is a multiple of 256");
+  if (L[n - 1].cols != 3) return fail(h, PT_ERR_UNSUPPORTED_MODEL, "NIF head must have 3 outputs (BGR)");
+  memset(&N, 0, sizeof(N));
+  N.n_layers = n;
+  const uint32_t in_steps_all = (E / 4 + 1) / 2;
+  uint32_t piece = 0, btile = 0;
+  head_in.clear();
+  for (uint32_t l = 0; l < n; ++l) {
+    const HostLayer& Y = L[l];
+    const bool head = (l == n - 1);
+    if (!head && Y.cols != H) return fail(h, PT_ERR_UNSUPPORTED_MODEL, "all hidden layers must have the same width");
+    bool concat = false;
+    uint32_t act_steps = 0;
+    if (l == 0) {
+      if (Y.rows != in_dim) return fail(h, PT_ERR_UNSUPPORTED_MODEL, "bad first layer shape");
+    } else if (Y.rows == H) {
+      act_steps = H / 32;
+    } else if (Y.rows == H + in_dim) {  // NifModel.cpp:305-308: x = concat(x, input)
+      act_steps = H / 32;
+      concat = true;
+    } else {
+      return fail(h, PT_ERR_UNSUPPORTED_MODEL, "layer input width is neither hidden nor hidden+features");
+    }
+    const uint32_t in_steps = (!head && (l == 0 || concat)) ? in_steps_all : 0;
+    const uint32_t ksteps = act_steps + in_steps;
+    const uint32_t nf16 = head ? 1u : H / 16;
+    N.piece_base[l] = piece;
+    N.bias_base[l] = btile;
+    if (concat) N.concat_mask |= 1u << l;
+    if (Y.relu) N.relu_mask |= 1u << l;
+    if (!Y.bias.empty()) N.bias_mask |= 1u << l;
+    wpack.resize((size_t)(piece + ksteps * nf16) * 512, 0);
+    for (uint32_t s = 0; s < ksteps; ++s)
+      for (uint32_t f = 0; f < nf16; ++f) {
+        uint16_t* dst = &wpack[(size_t)(piece + s * nf16 + f) * 512];
+        for (uint32_t lane = 0; lane < 64; ++lane) {
+          const uint32_t r = lane & 15, q = lane >> 4, col = 16 * f + r;
+          for (uint32_t e = 0; e < 8; ++e) {
+            uint32_t k;
+            bool zero = col >= Y.cols;
+            if (s < act_steps) {
+              k = 32 * s + (e < 4 ? 4 * q + e : 16 + 4 * q + (e - 4));
+            } else {
+              const uint32_t sp = s - act_steps, cd = q & 1, fr = 4 * (2 * sp + (q >> 1)) + (e & 3);
+              if (fr >= E) zero = true;
+              k = (concat ? H : 0) + (e < 4 ? 0 : 2 * E) + cd * E + fr;
+            }
+            dst[lane * 8 + e] = zero ? (uint16_t)0 : Y.kernel[(size_t)k * Y.cols + col];
+          }
+        }
+      }
+    if (head) {
+      head_piece_base = piece;
+      for (int o = 0; o < 3; ++o) head_bias[o] = Y.bias.empty() ? 0.f : host_h2f(Y.bias[o]);
+      if (concat) {
+        head_in.assign((size_t)in_dim * 4, 0.f);
+        for (uint32_t f = 0; f < in_dim; ++f)
+          for (int o = 0; o < 3; ++o) head_in[(size_t)f * 4 + o] = host_h2f(Y.kernel[(size_t)(H + f) * 3 + o]);
+      }
+    } else {
+      const uint32_t nj = H / 32;
+      bpack.resize((size_t)(btile + nj) * 32, 0);
+      for (uint32_t j = 0; j < nj; ++j)
+        for (uint32_t q = 0; q < 4; ++q)
+          for (uint32_t e = 0; e < 8; ++e) {
+            const uint32_t col = 32 * j + (e < 4 ? 4 * q + e : 16 + 4 * q + (e - 4));
+            bpack[(size_t)(btile + j) * 32 + q * 8 + e] = Y.bias.empty() ? (uint16_t)0 : Y.bias[col];
+          }
+      btile += nj;
+    }
+    piece += ksteps * nf16;
+  }
+  bpack.resize(bpack.size() + 32, 0);
+  return PT_OK;
+}
+
 #ifdef PTMI_DIAG_BUILD
 // The same network packed for nif_kernel_v4 (v_mfma_f32_16x16x32_f16, pt_nif16.h).  Piece (l, j, s, ft): lane
 // (r = lane & 15, qg = lane >> 4) holds W^T[32 j + 16 ft + r][k(qg, 0..7)] with
@@ -602,15 +701,17 @@ int launch_nif_wide(pt_handle h, const ptd::NifParams& N, int blocks) {
 }
 #endif
 
+#ifdef PTMI_DIAG_BUILD
+// ---- profiling build: the round-2 32x32x16 layer path (A/B baseline)
 template <int E>
-void launch_nifg_encode(pt_handle h, const ptd::NifParams& N, uint32_t tile0, uint32_t chunk) {
+void launch_nifg32_encode(pt_handle h, const ptd::NifParams& N, uint32_t tile0, uint32_t chunk) {
   hipLaunchKernelGGL((ptd::nifg_encode_kernel<E>), dim3((chunk + 3u) / 4u), dim3(256), 0, h->stream, N, h->d_tile_start, tile0, chunk,
                      h->d_gemm_feat);
 }
 
 // Wide networks, one launch per layer over chunks of the queue (pt_nif_gemm.h).  The number of queue tiles is only
 // known on the device, so chunks are launched up to the queue's capacity and those past its end return at once.
-int launch_nif_gemm(pt_handle h, const ptd::NifParams& N) {
+int launch_nif_gemm32(pt_handle h, const ptd::NifParams& N) {
   const uint32_t H = (uint32_t)h->nif_hidden, KS = H / 16, IS = (uint32_t)h->nif_emb / 4, NT = H / 32, FB = NT / 8;
   const uint32_t n_layers = N.n_layers, chunk = h->gemm_chunk;
   if (!chunk) return fail(h, PT_ERR_NOT_READY, "wide-NIF buffers are not allocated");
@@ -683,10 +784,10 @@ int launch_nif_gemm(pt_handle h, const ptd::NifParams& N) {
   for (uint64_t tile0 = 0; tile0 < max_tiles; tile0 += chunk) {
     G.tile0 = (uint32_t)tile0;
     switch (h->nif_emb) {
-      case 4: launch_nifg_encode<4>(h, N, G.tile0, chunk); break;
-      case 8: launch_nifg_encode<8>(h, N, G.tile0, chunk); break;
-      case 12: launch_nifg_encode<12>(h, N, G.tile0, chunk); break;
-      case 16: launch_nifg_encode<16>(h, N, G.tile0, chunk); break;
+      case 4: launch_nifg32_encode<4>(h, N, G.tile0, chunk); break;
+      case 8: launch_nifg32_encode<8>(h, N, G.tile0, chunk); break;
+      case 12: launch_nifg32_encode<12>(h, N, G.tile0, chunk); break;
+      case 16: launch_nifg32_encode<16>(h, N, G.tile0, chunk); break;
       default: return fail(h, PT_ERR_UNSUPPORTED_MODEL, "unsupported embedding dimension");
     }
     PT_HIP(hipGetLastError());
@@ -718,15 +819,112 @@ int launch_nif_gemm(pt_handle h, const ptd::NifParams& N) {
   return PT_OK;
 }
 
+#endif
+
+// Wide networks, one launch per layer over chunks of the queue (pt_nif_gemm.h).  The number of queue tiles is only
+// known on the device, so chunks are launched up to the queue's capacity and those past its end return at once.
+template <int E>
+void launch_nifg16_encode(pt_handle h, const ptd::NifParams& N, uint32_t tile0, uint32_t chunk) {
+  hipLaunchKernelGGL((ptd::nifg16_encode_kernel<E>), dim3((chunk + 3u) / 4u), dim3(256), 0, h->stream, N, h->d_tile_start, tile0, chunk,
+                     h->d_gemm_feat);
+}
+
+template <int FUSE>
+int launch_nifg16_layer(pt_handle h, const ptd::NifGemmParams& G, uint32_t grid) {
+  static std::atomic<unsigned long long> attr_set{0};
+  if (int rc = set_dynamic_lds(h, reinterpret_cast<const void*>(&ptd::nifg16_layer_kernel<FUSE, 0>), ptd::kGemmLdsBytes, attr_set)) return rc;
+#ifdef PTMI_DIAG_BUILD
+  // timing-only ablations / clock stamps of the profiling build, read per launch (PTMI_GEMM_DIAG: see the kernel's DIAG bits)
+  const int gdiag = getenv("PTMI_GEMM_DIAG") ? atoi(getenv("PTMI_GEMM_DIAG")) : 0;
+#define PT_LAYER16(D)                                                                                                          \
+  case D: {                                                                                                                    \
+    PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ptd::nifg16_layer_kernel<FUSE, D>),                               \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, ptd::kGemmLdsBytes));                               \
+    ptd::NifGemmParams GS = G;                                                                                                 \
+    GS.stamps = h->d_stamps;                                                                                                   \
+    hipLaunchKernelGGL((ptd::nifg16_layer_kernel<FUSE, D>), dim3(grid), dim3(512), ptd::kGemmLdsBytes, h->stream, GS);          \
+    PT_HIP(hipGetLastError());                                                                                                 \
+    return PT_OK;                                                                                                              \
+  }
+  switch (gdiag) { PT_LAYER16(1) PT_LAYER16(2) PT_LAYER16(3) PT_LAYER16(8) PT_LAYER16(32) default: break; }
+#undef PT_LAYER16
+#endif
+  hipLaunchKernelGGL((ptd::nifg16_layer_kernel<FUSE, 0>), dim3(grid), dim3(512), ptd::kGemmLdsBytes, h->stream, G);
+  PT_HIP(hipGetLastError());
+  return PT_OK;
+}
+
+int launch_nif_gemm(pt_handle h, const ptd::NifParams& N) {
+  const uint32_t H = (uint32_t)h->nif_hidden, KS = H / 32, IS = ((uint32_t)h->nif_emb / 4 + 1) / 2, NT = H / 32, FB = NT / 8;
+  const uint32_t n_layers = N.n_layers, chunk = h->gemm_chunk;
+  if (!chunk) return fail(h, PT_ERR_NOT_READY, "wide-NIF buffers are not allocated");
+  if (FB == 0 || NT % 8u) return fail(h, PT_ERR_UNSUPPORTED_MODEL, "layer-by-layer NIF path needs a hidden width that is a multiple of 256");
+  hipLaunchKernelGGL(ptd::nifg_scan_kernel, dim3(1), dim3(256), 0, h->stream, N.region_count, N.n_regions, h->d_tile_start);
+  PT_HIP(hipGetLastError());
+  const uint64_t max_tiles = (uint64_t)N.n_regions * ((N.region_cap + 31u) / 32u);
+  uint32_t grid = ((uint32_t)h->n_cus / (8u * FB)) * 8u * FB;
+  if (grid == 0) grid = 8u * FB;
+  ptd::NifGemmParams G{};
+  G.wpack = N.wpack;
+  G.bpack = N.bpack;
+  G.feat = h->d_gemm_feat;
+  G.act_stride = KS;
+  G.feat_stride = IS;
+  G.total_tiles = h->d_tile_start + N.n_regions;
+  G.chunk_tiles = chunk;
+  G.n_ftiles = NT;
+  G.head_piece_base = h->head_piece_base;
+  G.partial_stride = chunk * 32u;
+  const uint32_t lh = n_layers - 1;
+  ptd::NifHeadParams Hd{};
+  Hd.partial = h->d_head_partial;
+  Hd.slices = 2u * FB;
+  Hd.partial_stride = chunk * 32u;
+  Hd.in_weights = ((N.concat_mask >> lh) & 1u) ? h->d_head_in : nullptr;
+  Hd.n_in = (uint32_t)h->nif_emb;
+  Hd.bias0 = h->head_bias[0]; Hd.bias1 = h->head_bias[1]; Hd.bias2 = h->head_bias[2];
+  Hd.relu = (N.relu_mask >> lh) & 1u;
+  Hd.chunk_tiles = chunk;
+  for (uint64_t tile0 = 0; tile0 < max_tiles; tile0 += chunk) {
+    G.tile0 = (uint32_t)tile0;
+    switch (h->nif_emb) {
+      case 4: launch_nifg16_encode<4>(h, N, G.tile0, chunk); break;
+      case 8: launch_nifg16_encode<8>(h, N, G.tile0, chunk); break;
+      case 12: launch_nifg16_encode<12>(h, N, G.tile0, chunk); break;
+      case 16: launch_nifg16_encode<16>(h, N, G.tile0, chunk); break;
+      default: return fail(h, PT_ERR_UNSUPPORTED_MODEL, "unsupported embedding dimension");
+    }
+    PT_HIP(hipGetLastError());
+    for (uint32_t l = 0; l + 1 < n_layers; ++l) {
+      const bool concat = (N.concat_mask >> l) & 1u;
+      const bool last = l + 2 == n_layers;   // the head rides in this layer's epilogue
+      G.piece_base = N.piece_base[l];
+      G.bias_base = N.bias_base[l];
+      G.ks_act = l ? KS : 0u;
+      G.ks_in = (l == 0 || concat) ? IS : 0u;
+      G.relu = (N.relu_mask >> l) & 1u;
+      G.act_in = h->d_gemm_act[(l + 1u) & 1u];
+      G.act_out = last ? nullptr : h->d_gemm_act[l & 1u];
+      G.head_partial = last ? h->d_head_partial : nullptr;
+      if (int rc = last ? launch_nifg16_layer<1>(h, G, grid) : launch_nifg16_layer<0>(h, G, grid)) return rc;
+    }
+    Hd.tile0 = G.tile0;
+    hipLaunchKernelGGL(ptd::nifg16_finish_kernel, dim3((chunk + 7u) / 8u), dim3(256), 0, h->stream, N, Hd, h->d_tile_start);
+    PT_HIP(hipGetLastError());
+  }
+  return PT_OK;
+}
+
 int launch_nif(pt_handle h, const ptd::NifParams& N, int blocks) {
   if (h->nif_gemm) {
 #ifdef PTMI_DIAG_BUILD
     // A/B switch of the profiling build: the fused 64-sample kernel with activations in LDS
     static const bool fused = getenv("PTMI_NIF_WIDE") && !strcmp(getenv("PTMI_NIF_WIDE"), "fused");
-    if (fused && h->nif_emb == 12) {
+    if (fused && h->nif_emb == 12 && h->nif_gemm32) {
       if (h->nif_hidden == 1024) return launch_nif_wide<1024, 12>(h, N, blocks);
       if (h->nif_hidden == 512) return launch_nif_wide<512, 12>(h, N, blocks);
     }
+    if (h->nif_gemm32) return launch_nif_gemm32(h, N);
 #endif
     return launch_nif_gemm(h, N);
   }
@@ -864,6 +1062,7 @@ int pt_destroy(pt_handle h) {
   (void)hipFree(h->d_wpack); (void)hipFree(h->d_bpack);
   (void)hipFree(h->d_gemm_act[0]); (void)hipFree(h->d_gemm_act[1]); (void)hipFree(h->d_gemm_feat); (void)hipFree(h->d_tile_start);
   (void)hipFree(h->d_stamps);
+  (void)hipFree(h->d_head_partial); (void)hipFree(h->d_head_in);
   (void)hipFree(h->d_scratch);
   (void)hipFree(h->d_hdr_stage); (void)hipFree(h->d_hdr_gather); (void)hipFree(h->d_film);
   (void)hipFree(h->d_slot_check);
@@ -917,15 +1116,23 @@ int pt_upload_nif(pt_handle h, const pt_layer* layers, uint32_t n_layers, uint32
   if (rc) return rc;
   std::vector<uint16_t> wpack, bpack;
   ptd::NifParams N;
-  bool m16 = false;
+  bool m16 = false, gemm32 = false;
+  std::vector<float> head_in;
+  float head_bias[3] = {0, 0, 0};
+  uint32_t head_piece_base = 0;
 #ifdef PTMI_DIAG_BUILD
+  // A/B switch of the profiling build: PTMI_GEMM_SHAPE=32 keeps a wide network on the round-2 32x32x16 layer kernels
+  if (const char* k = getenv("PTMI_GEMM_SHAPE")) gemm32 = plan.gemm && atoi(k) == 32;
   // A/B switch of the profiling build: PTMI_NIF_KERNEL=v4 packs for the 16x16x32 kernel (pt_nif16.h).  Measured equal
   // to v3 in NIF time within 1-2 %, but its 230 VGPRs leave no room for the trace kernel's waves beside it, so
   // the step is 1.5 % slower end to end (profiles/r01_c_nif_ablation.txt); v3 stays the product kernel.
   if (const char* k = getenv("PTMI_NIF_KERNEL")) m16 = strcmp(k, "v4") == 0 && plan.Hp == 320 && plan.Ep == 12 && n_layers <= 8;
-  rc = m16 ? pack_nif16(h, padded, plan.Ep, wpack, bpack, N) : pack_nif(h, padded, plan.Ep, wpack, bpack, N);
+  rc = m16 ? pack_nif16(h, padded, plan.Ep, wpack, bpack, N)
+       : (plan.gemm && !gemm32) ? pack_nif_g16(h, padded, plan.Ep, wpack, bpack, N, head_in, head_bias, head_piece_base)
+                                : pack_nif(h, padded, plan.Ep, wpack, bpack, N);
 #else
-  rc = pack_nif(h, padded, plan.Ep, wpack, bpack, N);
+  rc = plan.gemm ? pack_nif_g16(h, padded, plan.Ep, wpack, bpack, N, head_in, head_bias, head_piece_base)
+                 : pack_nif(h, padded, plan.Ep, wpack, bpack, N);
 #endif
   if (rc) return rc;
   PT_HIP(hipSetDevice(h->cfg.device));
@@ -950,7 +1157,9 @@ int pt_upload_nif(pt_handle h, const pt_layer* layers, uint32_t n_layers, uint32
     if (const char* c = getenv("PTMI_GEMM_CHUNK")) chunk = (uint32_t)atoi(c) / 8u * 8u;   // chunk-size sweep of the profiling build
     if (chunk == 0) chunk = 8;
 #endif
-    const size_t act_bytes = (size_t)chunk * (plan.Hp / 16) * 1024, feat_bytes = (size_t)chunk * (plan.Ep / 4) * 1024 + 1024;   // + one piece: the paired loader reads one past an odd k-step count
+    // activations: Hp / 32 k-steps x 2 KiB per queue tile; features: ceil(Ep / 8) k-steps x 2 KiB (the 32-shape kernels of the
+    // profiling build use Ep / 4 pieces of 1 KiB and may read one piece past an odd count: the larger of the two + slack)
+    const size_t act_bytes = (size_t)chunk * (plan.Hp / 16) * 1024, feat_bytes = (size_t)chunk * ((plan.Ep + 7) / 8) * 2048 + 2048;
     for (int i = 0; i < 2; ++i) {
       if (h->d_gemm_act[i]) PT_HIP(hipFree(h->d_gemm_act[i]));
       h->d_gemm_act[i] = nullptr;
@@ -961,6 +1170,18 @@ int pt_upload_nif(pt_handle h, const pt_layer* layers, uint32_t n_layers, uint32
     h->d_gemm_feat = nullptr;
     PT_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_gemm_feat), feat_bytes));
     if (!h->d_tile_start) PT_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_tile_start), (ptd::kMaxRegions + 1) * 4));
+    // fused head: partial sums of the 2 x (Hp / 256) slices, and the head's feature-input weights if it concatenates them
+    if (h->d_head_partial) PT_HIP(hipFree(h->d_head_partial));
+    h->d_head_partial = nullptr;
+    PT_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_head_partial), (size_t)2 * (plan.Hp / 256) * chunk * 32 * sizeof(float4)));
+    if (h->d_head_in) PT_HIP(hipFree(h->d_head_in));
+    h->d_head_in = nullptr;
+    if (!head_in.empty()) {
+      PT_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_head_in), head_in.size() * sizeof(float)));
+      PT_HIP(hipMemcpy(h->d_head_in, head_in.data(), head_in.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    memcpy(h->head_bias, head_bias, sizeof(head_bias));
+    h->head_piece_base = head_piece_base;
 #ifdef PTMI_DIAG_BUILD
     if (!h->d_stamps) { PT_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_stamps), 256 * 8)); PT_HIP(hipMemset(h->d_stamps, 0, 256 * 8)); }
 #endif
@@ -970,6 +1191,7 @@ int pt_upload_nif(pt_handle h, const pt_layer* layers, uint32_t n_layers, uint32
   h->nif_hidden = (int)plan.Hp;
   h->nif_emb = (int)plan.Ep;
   h->nif_gemm = plan.gemm;
+  h->nif_gemm32 = gemm32;
   h->nif_m16 = m16;
   h->nif_flops = flops;
   h->nif_valid = true;

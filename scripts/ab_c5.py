@@ -1,0 +1,56 @@
+"""Same-process A/B of the wide-NIF layer path (BASELINE config C5: NIF 8 x 1024): the round-2 32x32x16 kernels
+(diag/pt_nif_gemm32.h, selected with PTMI_GEMM_SHAPE=32 while the weights are uploaded) against the 16x16x32 kernels with
+the fused head (pt_nif_gemm.h), interleaved round by round on one device (cdna_hip_programming.md section 5.4 rule 24).
+Loads libptmi_diag.so.  usage: python scripts/ab_c5.py [rounds] [spp] [name=ENV:VAL,...]   (extra variants of the 16 path)
+Prints per variant the NIF TFLOP/s (escaped x FLOP / sum of NIF-stage HIP-event time) and Mpath-samples/s of every round."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ipu_path_trace_amd import nif_assets as A  # noqa: E402
+from ipu_path_trace_amd import ptmi  # noqa: E402
+
+args = sys.argv[1:]
+rounds = int(args.pop(0)) if args and args[0].isdigit() else 4
+spp = int(args.pop(0)) if args and args[0].isdigit() else 30
+extra = []
+for a in args:
+    name, _, env = a.partition("=")
+    extra.append((name, dict(x.split(":") for x in env.split(",") if x)))
+hidden = int(os.environ.get("AB_HIDDEN", "1024"))
+layers = int(os.environ.get("AB_LAYERS", "8"))
+W, H = 1104, 1000
+L = A.synthetic_nif(hidden=hidden, layer_count=layers)
+
+
+def make(shape32):
+    if shape32:
+        os.environ["PTMI_GEMM_SHAPE"] = "32"
+    r = ptmi.Renderer(W, H, max_path_length=8, diag=True)
+    r.init_nif_weights(L, 12, A.URBAN_ALLEY_META["max"], A.folded_mean())
+    os.environ.pop("PTMI_GEMM_SHAPE", None)
+    r.init_render_settings(samples_per_step=spp)
+    r.setup(ptmi.worklist(W, H))
+    return r
+
+
+variants = [("mfma32x32x16", make(True), {}), ("mfma16x16x32", make(False), {})] + [(n, None, kv) for n, kv in extra]
+variants = [(n, r if r is not None else variants[1][1], kv) for n, r, kv in variants]
+keys = sorted({k for _, _, kv in variants for k in kv})
+res = {n: [] for n, _, _ in variants}
+for rd in range(rounds + 1):
+    for name, r, kv in variants:
+        for k in keys:
+            os.environ.pop(k, None)
+        os.environ.update(kv)
+        t = time.time()
+        r.path_trace()
+        dt = time.time() - t
+        st = r.stats()
+        if rd:   # round 0 warms up
+            res[name].append((st.escaped * st.nif_flops_per_sample / (st.nif_ms * 1e-3) / 1e12, st.paths / dt / 1e6, st.nif_ms))
+for name, _, _ in variants:
+    v = res[name]
+    print("%-14s NIF TFLOP/s %s | Mpath/s %s | nif ms %s" % (
+        name, " ".join("%7.1f" % x[0] for x in v), " ".join("%6.2f" % x[1] for x in v), " ".join("%7.1f" % x[2] for x in v)), flush=True)
