@@ -59,11 +59,14 @@ struct NifGemmParams {
   uint32_t partial_stride;       // samples per slice (= chunk_tiles * 32)
 };
 
-constexpr int kGemmStages = 4;                  // ring slots
-constexpr int kGemmStageBytes = 32 * 1024;      // one k-step of 32: 16 A pieces + 16 B pieces
+constexpr int kGemmStages = 4;                  // (32-shape kernels of the profiling build: ring slots of A + B)
+constexpr int kGemmStageBytes = 32 * 1024;      // (32-shape kernels: one stage, 16 A pieces + 16 B pieces)
+constexpr int kGemmASlots = 4;                  // ring of weight half-stages (16 pieces = 16 KiB each)
+constexpr int kGemmBSlots = 4;                  // ring of activation half-stages (5 = "B leads", measured below: no gain)
+constexpr int kGemmHalfBytes = 16 * 1024;
 constexpr int kGemmBiasBytes = 4096;            // up to 64 output groups of 32 features
 constexpr int kGemmHeadBytes = 8192;            // the head's 8 pieces of one 256-feature block
-constexpr int kGemmLdsBytes = kGemmBiasBytes + kGemmHeadBytes + kGemmStages * kGemmStageBytes;
+constexpr int kGemmLdsBytes = kGemmBiasBytes + kGemmHeadBytes + (kGemmASlots + 5) * kGemmHalfBytes;   // 156 KiB of 160 (room for the B-leads build)
 
 // Tiles of the queue in this chunk (0 if the queue ends before it).
 __device__ __forceinline__ uint32_t chunk_tile_count(const uint32_t* total_tiles, uint32_t tile0, uint32_t chunk_tiles) {
@@ -94,22 +97,39 @@ __device__ __forceinline__ uint32_t chunk_tile_count(const uint32_t* total_tiles
 //   waves 4-7 (one phase late)     B-pair, read    MFMA q0(S)      A-pair, wait,   MFMA q1(S)      B-pair, read
 //                                  A, B (S)                        read A'(S)                      A, B (S+1)
 //
+// Where the time goes (round 3, profiles/r03_c5_ablation.txt: in-kernel s_memtime / s_memrealtime stamps, timing-only
+// builds).  With every load redirected to an L2-hot piece the kernel needs exactly the cycles it needs with no loads at all
+// (MFMA pipe 78 % busy inside a block) -- the LDS-DMA issue, the ring and the barriers cost no cycles -- but runs at
+// 1.85 GHz instead of 2.18: moving 32 KiB per stage L2 -> LDS -> registers is paid in clock (power), not in stalls.  Fed
+// from memory, the activation stream adds 13 % cycles (the weights, L2-resident, add none) while the clock recovers to
+// 2.0-2.1 GHz: the chip is power-limited either way.  Tried against the activation stalls, all within +-0.5 %: an
+// activation ring one slot deeper than the weight ring ("B leads": RB = 5, DIAG bit 9 selects it; a wave's vector-memory
+// operations retire in order, so the counted wait for stage S + 1 covers every older load and B can lead A by one stage
+// at most), write-through (sc1) or non-temporal output stores (bits 10 / 11), chunks small enough for both activation
+// buffers to stay in the Infinity Cache.  One workgroup taking the four feature blocks of its sample block in turn
+// instead of four neighbours sharing them through L2 (bit 12): 16 % slower.
+//
 // q0 = feature tiles 0-3 of the wave x its four sample tiles, q1 = feature tiles 4-7 x the same four (the B fragments
 // stay, the A fragments are re-read: A').  "wait" = my pieces of stage S + 1 have landed (counted vmcnt); the whole of
 // stage S + 1 is certified (both halves have waited by the end of phase 4S+2) before its first reader (waves 0-3 in
 // phase 4S+3).  The slot of stage S + 3 is that of stage S - 1, whose last readers finished in phase 4S-1.
 // DIAG (timing-only builds, results invalid): bit 0 = no loads into the ring, bit 1 = no LDS reads of fragments,
-// bit 3 = every load from one L2-hot piece.  Bit 5 (valid results): in-kernel clock stamps of workgroup 0.
+// bit 3 = every load from one L2-hot piece, bit 4 = activation loads from one L2-hot piece, bit 6 / 7 = no weight / no activation loads, bit 8 = the activation pair as plain
+// loads into (unused) registers instead of LDS-DMA.  Bit 5 (valid results): in-kernel clock stamps of workgroup 0.
 template <int FUSE_HEAD, int DIAG>
 __global__ __launch_bounds__(512, 2) void nifg16_layer_kernel(const NifGemmParams P) {
-  constexpr int R = kGemmStages;
+  constexpr int RA = kGemmASlots;
+  constexpr int RB = (DIAG & 512) ? 5 : kGemmBSlots;   // DIAG bit 9 (valid results): the activation ring one slot deeper, its loads one stage further ahead
+  constexpr int LEAD = RB - RA;
   constexpr int kStores = FUSE_HEAD ? 4 : 16;   // vector-memory stores per wave and block (they share the vmcnt queue)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* bias_lds = smem;
   char* head_lds = smem + kGemmBiasBytes;
-  char* ring = head_lds + kGemmHeadBytes;
-  const uint32_t ring_lds = __builtin_amdgcn_readfirstlane(
-      (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring);
+  char* ring_a = head_lds + kGemmHeadBytes;
+  char* ring_b = ring_a + RA * kGemmHalfBytes;
+  const uint32_t ring_a_lds = __builtin_amdgcn_readfirstlane(
+      (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring_a);
+  const uint32_t ring_b_lds = ring_a_lds + RA * kGemmHalfBytes;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave & 1, wn = wave >> 1;
@@ -121,10 +141,19 @@ __global__ __launch_bounds__(512, 2) void nifg16_layer_kernel(const NifGemmParam
   const uint32_t FB = P.n_ftiles / 8u;                     // feature blocks of 256
   const uint32_t NF16 = P.n_ftiles * 2u;                   // 16-feature tiles of the layer
   const uint32_t xcd = blockIdx.x & 7u, cidx = blockIdx.x >> 3, cpx = gridDim.x >> 3;
-  const uint32_t fb = cidx % FB, sbi0 = cidx / FB, spx = cpx / FB;
-  if (xcd + 8u * sbi0 >= nsb) return;                      // nothing for this workgroup (uniform)
+  const uint32_t fb0 = cidx % FB, sbi0 = cidx / FB, spx = cpx / FB;
+  // Block it of this workgroup.  Product: the FB feature blocks of a sample block are FB neighbouring workgroups (same XCD,
+  // running at the same time).  DIAG bit 12 (valid results, FUSE_HEAD = 0 only): one workgroup takes the FB feature blocks
+  // of its sample block one after the other.
+  constexpr bool kSeqFb = (DIAG & 4096) != 0 && !FUSE_HEAD;
+  auto blk_fb = [&](uint32_t it) -> uint32_t { return kSeqFb ? it % FB : fb0; };
+  auto blk_sb = [&](uint32_t it) -> uint32_t { return kSeqFb ? xcd + 8u * (cidx + cpx * (it / FB)) : xcd + 8u * (sbi0 + spx * it); };
+  if (blk_sb(0) >= nsb) return;                            // nothing for this workgroup (uniform)
   const uint32_t nst = P.ks_act + P.ks_in;                 // stages = k-steps
 
+  // (DIAG bits 10 / 11: the output stores through a buffer descriptor, for their cache-policy bits)
+  const auto out_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(P.act_out ? P.act_out : P.act_in), 0, 0x7fffffff, 0x00020000);
+  const uint32_t relu_floor = P.relu ? 0u : 0xfc00fc00u;   // packed fp16 pair
   unsigned long long t_cycles = 0, t_real = 0;
   if constexpr (DIAG & 32) {
     if (blockIdx.x == 0 && threadIdx.x == 0) { t_cycles = __builtin_amdgcn_s_memtime(); t_real = __builtin_amdgcn_s_memrealtime(); }
@@ -133,75 +162,92 @@ __global__ __launch_bounds__(512, 2) void nifg16_layer_kernel(const NifGemmParam
   for (uint32_t i = threadIdx.x; i < P.n_ftiles * 4u; i += 512u)
     reinterpret_cast<uint4*>(bias_lds)[i] = P.bpack[(size_t)P.bias_base * 4u + i];
   if constexpr (FUSE_HEAD) {   // the head's pieces of this feature block: k-steps 8 fb .. 8 fb + 7
-    reinterpret_cast<uint4*>(head_lds)[threadIdx.x] = P.wpack[((size_t)P.head_piece_base + 8u * fb) * 64u + threadIdx.x];
+    reinterpret_cast<uint4*>(head_lds)[threadIdx.x] = P.wpack[((size_t)P.head_piece_base + 8u * fb0) * 64u + threadIdx.x];
   }
   __syncthreads();
 
-  // ---- loader: wave w loads weight tiles 2w, 2w+1 and sample tiles 2w, 2w+1 of stage (pf_it, pf_st) -> ring slot pf_q % R
+  // ---- loader: wave w loads weight tiles 2w, 2w+1 (cursor pa) and sample tiles 2w, 2w+1 (cursor pb) of a stage into the
+  // wave's 2 KiB of that operand's ring slot
   const uint32_t lane16 = (uint32_t)lane * 16u;
-  uint32_t pf_it = 0, pf_st = 0, pf_q = 0;
-  auto issue_pair = [&](int which) {   // 0: weights, 1: activations
-    const char* base;
-    if (which == 0) {
-      base = reinterpret_cast<const char*>(P.wpack) + ((size_t)(P.piece_base + pf_st * NF16 + fb * 16u + 2u * (uint32_t)wave) << 10);
-    } else {
-      const uint32_t t = (xcd + 8u * (sbi0 + spx * pf_it)) * 8u + (uint32_t)wave;
-      base = (pf_st < P.ks_act) ? reinterpret_cast<const char*>(P.act_in) + (((size_t)t * P.act_stride + pf_st) << 11)
-                                : reinterpret_cast<const char*>(P.feat) + (((size_t)t * P.feat_stride + (pf_st - P.ks_act)) << 11);
+  struct Cursor { uint32_t it, st, slot; };
+  Cursor pa{0, 0, 0}, pb{0, 0, 0};
+  auto advance = [&](Cursor& c, uint32_t slots) {
+    c.slot = (c.slot + 1u == slots) ? 0u : c.slot + 1u;
+    c.st += 1;
+    if (c.st == nst) {
+      if (blk_sb(c.it + 1u) < nsb) { c.it += 1; c.st = 0; }
+      else c.st = nst - 1u;   // past the last block: the same stage again (in bounds, never multiplied)
     }
+  };
+  auto issue_a = [&]() {
+    const char* base = reinterpret_cast<const char*>(P.wpack) + ((size_t)(P.piece_base + pa.st * NF16 + blk_fb(pa.it) * 16u + 2u * (uint32_t)wave) << 10);
     if constexpr (DIAG & 8) base = reinterpret_cast<const char*>(P.wpack) + ((size_t)wave << 11);
-    const uint32_t dst = ring_lds + (pf_q % R) * kGemmStageBytes + (uint32_t)which * 16384u + ((uint32_t)wave << 11);
-    if constexpr (!(DIAG & 1)) glds16x2(base, lane16, dst);
+    const uint32_t dst = ring_a_lds + pa.slot * kGemmHalfBytes + ((uint32_t)wave << 11);
+    if constexpr (!(DIAG & 1) && !(DIAG & 64)) glds16x2(base, lane16, dst);
+    advance(pa, RA);
   };
-  auto stage_issued = [&]() {
-    pf_q += 1;
-    pf_st += 1;
-    if (pf_st == nst) {
-      if (xcd + 8u * (sbi0 + spx * (pf_it + 1u)) < nsb) { pf_it += 1; pf_st = 0; }
-      else pf_st = nst - 1u;   // past the last block: the same stage again (in bounds, never multiplied)
+  auto issue_b = [&]() {
+    const uint32_t t = blk_sb(pb.it) * 8u + (uint32_t)wave;
+    const char* base = (pb.st < P.ks_act) ? reinterpret_cast<const char*>(P.act_in) + (((size_t)t * P.act_stride + pb.st) << 11)
+                                          : reinterpret_cast<const char*>(P.feat) + (((size_t)t * P.feat_stride + (pb.st - P.ks_act)) << 11);
+    if constexpr ((DIAG & 8) || (DIAG & 16)) base = reinterpret_cast<const char*>(P.wpack) + ((size_t)wave << 11);
+    const uint32_t dst = ring_b_lds + pb.slot * kGemmHalfBytes + ((uint32_t)wave << 11);
+    if constexpr ((DIAG & 256) != 0) {                             // timing only: the activation pair as plain loads to registers
+      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+      u32x4 d0, d1;
+      asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:1024"
+                   : "=&v"(d0), "=&v"(d1) : "v"(lane16), "s"(reinterpret_cast<uint64_t>(base)) : "memory");
+      asm volatile("" ::"v"(d0), "v"(d1));
+    } else if constexpr (!(DIAG & 1) && !(DIAG & 128)) {
+      glds16x2(base, lane16, dst);
     }
+    advance(pb, RB);
   };
+  // prologue: A(0), B(0), ..., A(RA - 2), B(RA - 2), then the stages B leads by
 #pragma unroll
-  for (int k = 0; k < R - 1; ++k) {
-    issue_pair(0);
-    issue_pair(1);
-    stage_issued();
-  }
+  for (int k = 0; k < RA - 1; ++k) { issue_a(); issue_b(); }
+#pragma unroll
+  for (int k = 0; k < LEAD; ++k) issue_b();
 
   half8 FA[4], FBv[4];
-  auto read_a = [&](const uint4* slot, int half) __attribute__((always_inline)) {
+  auto read_a = [&](uint32_t slot, int half) __attribute__((always_inline)) {
     if constexpr (!(DIAG & 2)) {
+      const uint4* p = reinterpret_cast<const uint4*>(ring_a + slot * kGemmHalfBytes) + lane;
 #pragma unroll
-      for (int a = 0; a < 4; ++a) FA[a] = as_half8(slot[(8 * wm + 4 * half + a) * 64]);
+      for (int a = 0; a < 4; ++a) FA[a] = as_half8(p[(8 * wm + 4 * half + a) * 64]);
     }
   };
-  auto read_b = [&](const uint4* slot) __attribute__((always_inline)) {
+  auto read_b = [&](uint32_t slot) __attribute__((always_inline)) {
     if constexpr (!(DIAG & 2)) {
+      const uint4* p = reinterpret_cast<const uint4*>(ring_b + slot * kGemmHalfBytes) + lane;
 #pragma unroll
-      for (int b = 0; b < 4; ++b) FBv[b] = as_half8(slot[1024 + (4 * wn + b) * 64]);
+      for (int b = 0; b < 4; ++b) FBv[b] = as_half8(p[(4 * wn + b) * 64]);
     }
   };
   auto phase_end = [&]() __attribute__((always_inline)) {
     asm volatile("s_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);   // nothing, MFMAs included, moves across a phase boundary
   };
-  uint32_t q = 0;            // consumer stage
+  uint32_t qa = 0, qb = 0;   // ring slots of the consumer's stage
   uint32_t since_store = 2;  // stages since the last epilogue's stores entered the vmcnt queue
-  // Counted wait of load phase A: my pieces of stage q + 1 have landed when at most the pair just issued for stage q + 3
-  // and the four loads of stage q + 2 are outstanding (the previous block's stores count while they are younger than the
-  // stage awaited).
+  // Counted wait of load phase A, issued right after A(q + 3): my pieces of stage q + 1 have landed when at most the loads
+  // younger than A(q + 1) are outstanding -- A(q + 2), A(q + 3) and B(q + 2 + LEAD), B(q + 3 + LEAD)... i.e. two A pairs and
+  // two B pairs whatever the lead (B(q + 1 + LEAD) was issued just before A(q + 2)'s stage; with the lead it is B(q + 2) and
+  // B(q + 3) that follow A(q + 1), without it B(q + 1) is older and B(q + 2) younger: one B pair less) -- plus the previous
+  // block's stores while they are younger than the stage awaited.
+  constexpr int kYoung = 2 * (2 + 1 + LEAD);   // loads issued after A(q + 1), up to and including A(q + 3)
   auto wait_ahead = [&]() __attribute__((always_inline)) {
-    if (nst < 4u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (since_store < 2u) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + kStores) : "memory");
-    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if (nst < 6u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (since_store < 2u) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kYoung + kStores) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kYoung) : "memory");
   };
 
-  {  // prologue: stage 0 certified here, the next one by the first stage's own wait
-    if (nst < 4u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  {  // prologue: stage 0 certified here (everything issued after B(0) may be outstanding), the next one by the first stage's wait
+    if (nst < 6u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (2 * (RA - 2) + LEAD)) : "memory");
     phase_end();
-    read_a(reinterpret_cast<const uint4*>(ring) + lane, 0);
-    read_b(reinterpret_cast<const uint4*>(ring) + lane);
+    read_a(0, 0);
+    read_b(0);
   }
   if constexpr (DIAG & 2) {
 #pragma unroll
@@ -212,7 +258,7 @@ __global__ __launch_bounds__(512, 2) void nifg16_layer_kernel(const NifGemmParam
   if (second) phase_end();
 
   for (uint32_t it = 0;; ++it) {
-    const uint32_t sb = xcd + 8u * (sbi0 + spx * it);
+    const uint32_t sb = blk_sb(it), fb = blk_fb(it);
     if (sb >= nsb) break;
     f32x4 acc[8][4];
 #pragma unroll
@@ -229,9 +275,9 @@ __global__ __launch_bounds__(512, 2) void nifg16_layer_kernel(const NifGemmParam
     };
 
     for (uint32_t st = 0; st < nst; ++st) {
-      const uint4* slot = reinterpret_cast<const uint4*>(ring + (q % R) * kGemmStageBytes) + lane;
-      const uint4* next = reinterpret_cast<const uint4*>(ring + ((q + 1u) % R) * kGemmStageBytes) + lane;
-      q += 1;
+      const uint32_t slot_a = qa;
+      qa = (qa + 1u == RA) ? 0u : qa + 1u;
+      qb = (qb + 1u == RB) ? 0u : qb + 1u;
       // ---- MFMA phase, quadrant 0
       __builtin_amdgcn_s_setprio(1);
       multiply(IC<0>{});
@@ -239,8 +285,8 @@ __global__ __launch_bounds__(512, 2) void nifg16_layer_kernel(const NifGemmParam
       phase_end();
       // ---- load phase A: the A fragments of quadrant 1 (read first: their LDS latency passes under the LDS-DMA issue and
       // the counted wait), weights of the stage three ahead, certify my share of the next stage
-      read_a(slot, 1);
-      issue_pair(0);
+      read_a(slot_a, 1);
+      issue_a();
       wait_ahead();
       phase_end();
       // ---- MFMA phase, quadrant 1
@@ -250,10 +296,9 @@ __global__ __launch_bounds__(512, 2) void nifg16_layer_kernel(const NifGemmParam
       phase_end();
       // ---- load phase B: fragments of the next stage's quadrant 0 (certified by the barrier that ended this wave's
       // previous load phase at the latest), activations of the stage three ahead
-      read_a(next, 0);
-      read_b(next);
-      issue_pair(1);
-      stage_issued();
+      read_a(qa, 0);
+      read_b(qb);
+      issue_b();
       phase_end();
       since_store += 1;
     }
@@ -278,17 +323,29 @@ __global__ __launch_bounds__(512, 2) void nifg16_layer_kernel(const NifGemmParam
 #pragma unroll
         for (int i = 0; i < 4; ++i) { o[i] = (_Float16)acc[2 * s][b][i]; o[4 + i] = (_Float16)acc[2 * s + 1][b][i]; }
         o = o + bias;
-        if (P.relu) {
-          const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-          o = __builtin_elementwise_max(o, z);
+        {   // ReLU as one v_pk_max_f16 per register against a uniform floor: 0, or -inf for a linear layer (max(x, -inf) = x)
+          typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+          union { half8 hh; u32x4 u; } c;
+          c.hh = o;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) asm("v_pk_max_f16 %0, %1, %2" : "=v"(c.u[i]) : "v"(c.u[i]), "s"(relu_floor));
+          o = c.hh;
         }
         if constexpr (FUSE_HEAD) {
           hacc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hw, o, hacc[b], 0, 0, 0);
         } else {
           const uint32_t t16 = sb * 16u + 4u * wn + b;
-          union { half8 hh; uint4 u; } c0;
-          c0.hh = o;
-          P.act_out[(((size_t)(t16 >> 1) * P.act_stride + j) * 2u + (t16 & 1u)) * 64u + lane] = c0.u;
+          if constexpr ((DIAG & 3072) != 0) {   // bit 10: sc1 (write-through, the line is not kept in L2), bit 11: nt
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            union { half8 hh; u32x4 u; } c1;
+            c1.hh = o;
+            const uint32_t off = ((((t16 >> 1) * P.act_stride + j) * 2u + (t16 & 1u)) * 64u + (uint32_t)lane) * 16u;
+            __builtin_amdgcn_raw_buffer_store_b128(c1.u, out_rsrc, off, 0, (DIAG & 1024) ? 16 : 2);
+          } else {
+            union { half8 hh; uint4 u; } c0;
+            c0.hh = o;
+            P.act_out[(((size_t)(t16 >> 1) * P.act_stride + j) * 2u + (t16 & 1u)) * 64u + lane] = c0.u;
+          }
         }
       }
     }

@@ -846,7 +846,8 @@ int launch_nifg16_layer(pt_handle h, const ptd::NifGemmParams& G, uint32_t grid)
     PT_HIP(hipGetLastError());                                                                                                 \
     return PT_OK;                                                                                                              \
   }
-  switch (gdiag) { PT_LAYER16(1) PT_LAYER16(2) PT_LAYER16(3) PT_LAYER16(8) PT_LAYER16(32) default: break; }
+  switch (gdiag) { PT_LAYER16(1) PT_LAYER16(2) PT_LAYER16(3) PT_LAYER16(8) PT_LAYER16(32) PT_LAYER16(64) PT_LAYER16(128) PT_LAYER16(256)
+                   PT_LAYER16(16) PT_LAYER16(33) PT_LAYER16(40) PT_LAYER16(48) PT_LAYER16(160) PT_LAYER16(512) PT_LAYER16(544) PT_LAYER16(1024) PT_LAYER16(2048) PT_LAYER16(1056) PT_LAYER16(4096) PT_LAYER16(5120) default: break; }
 #undef PT_LAYER16
 #endif
   hipLaunchKernelGGL((ptd::nifg16_layer_kernel<FUSE, 0>), dim3(grid), dim3(512), ptd::kGemmLdsBytes, h->stream, G);

@@ -221,7 +221,7 @@ private:
       if (number(1.f, 65535.f, false, v) && v == std::floor(v)) { state.interactiveSamples = (std::uint32_t)v; stateUpdated = true; }
       else if (v != std::floor(v)) pt_log::warn_("User interface: '{}' rejected (want a whole number); state unchanged", line);
     }
-    else if (!name.empty()) pt_log::warn_("User interface: unknown command '{}'", name);
+    else if (!name.empty()) pt_log::warn_("User interface: unknown command '{}'", name.substr(0, 64));
   }
 
   bool sendAll(const void* p, std::size_t n) {

@@ -24,19 +24,24 @@ W, H = 1104, 1000
 L = A.synthetic_nif(hidden=hidden, layer_count=layers)
 
 
-def make(shape32):
+def make(shape32, chunk=None):
     if shape32:
         os.environ["PTMI_GEMM_SHAPE"] = "32"
+    if chunk:
+        os.environ["PTMI_GEMM_CHUNK"] = str(chunk)
     r = ptmi.Renderer(W, H, max_path_length=8, diag=True)
     r.init_nif_weights(L, 12, A.URBAN_ALLEY_META["max"], A.folded_mean())
     os.environ.pop("PTMI_GEMM_SHAPE", None)
+    os.environ.pop("PTMI_GEMM_CHUNK", None)
     r.init_render_settings(samples_per_step=spp)
     r.setup(ptmi.worklist(W, H))
     return r
 
 
-variants = [("mfma32x32x16", make(True), {}), ("mfma16x16x32", make(False), {})] + [(n, None, kv) for n, kv in extra]
-variants = [(n, r if r is not None else variants[1][1], kv) for n, r, kv in variants]
+variants = [("mfma32x32x16", make(True), {}), ("mfma16x16x32", make(False), {})]
+for n, kv in extra:   # CHUNK:<tiles> in a variant makes its own renderer (the chunk size is fixed when the weights are uploaded)
+    chunk = kv.pop("CHUNK", None)
+    variants.append((n, make(False, int(chunk)) if chunk else variants[1][1], kv))
 keys = sorted({k for _, _, kv in variants for k in kv})
 res = {n: [] for n, _, _ in variants}
 for rd in range(rounds + 1):
@@ -50,6 +55,13 @@ for rd in range(rounds + 1):
         st = r.stats()
         if rd:   # round 0 warms up
             res[name].append((st.escaped * st.nif_flops_per_sample / (st.nif_ms * 1e-3) / 1e12, st.paths / dt / 1e6, st.nif_ms))
+            if int(kv.get("PTMI_GEMM_DIAG", "0")) & 32:   # in-kernel clock of the last layer launch: shader cycles per 100 MHz tick
+                import ctypes as C
+                out = (C.c_ulonglong * 256)()
+                assert ptmi.load_library(diag=True).pt_diag_stamps(r.handle, out) == 0
+                if out[1]:
+                    print("  %s: in-kernel clock %.3f GHz (%d shader cycles in %d ticks of 10 ns, workgroup 0 of the last layer launch)"
+                          % (name, out[0] / out[1] * 0.1, out[0], out[1]), flush=True)
 for name, _, _ in variants:
     v = res[name]
     print("%-14s NIF TFLOP/s %s | Mpath/s %s | nif ms %s" % (

@@ -42,12 +42,16 @@ def main():
             avg_ns[row["Name"]] = float(row["AverageNs"])
     fetch, write, mfma = (counters(os.path.join(src, d)) for d in ("pmc_fetch", "pmc_write", "pmc_mfma"))
     MiB = 1 << 20
-    algorithmic = {"nifg_layer_kernel": ("hidden layer of a full chunk: 256 MiB activations in + 256 MiB out + 2 MiB weights", 514 * MiB),
-                   "nifg_head_kernel": ("256 MiB activations in + 1.5 MiB of results", int(257.5 * MiB)),
-                   "nifg_encode_kernel": ("1 MiB of queue coordinates in + 12 MiB of feature pieces out", 13 * MiB)}
+    algorithmic = {"nifg16_layer_kernel<0": ("hidden layer of a full chunk: 256 MiB activations in + 256 MiB out + 2 MiB weights", 514 * MiB),
+                   "nifg16_layer_kernel<1": ("last hidden layer of a full chunk, head fused: 256 MiB activations in + 2 MiB weights + 16 MiB of head partial sums out", 274 * MiB),
+                   "nifg16_finish_kernel": ("16 MiB of head partial sums + 1 MiB of queue coordinates in + 1.5 MiB of results out", int(18.5 * MiB)),
+                   "nifg16_encode_kernel": ("1 MiB of queue coordinates in + 16 MiB of feature pieces out", 17 * MiB),
+                   "nifg_layer_kernel": ("(round-2 kernel) hidden layer of a full chunk: 256 MiB activations in + 256 MiB out + 2 MiB weights", 514 * MiB),
+                   "nifg_head_kernel": ("(round-2 kernel) 256 MiB activations in + 1.5 MiB of results", int(257.5 * MiB)),
+                   "nifg_encode_kernel": ("(round-2 kernel) 1 MiB of queue coordinates in + 12 MiB of feature pieces out", 13 * MiB)}
     doc = {"source": "scripts/pmc_c5.sh %s over scripts/bench_c5.py 8 (1104x1000, NIF 8x1024, 8 spp); median over the full-size "
-                     "dispatches of each kernel; layer 0 (48 -> 1024) and the hidden layers share nifg_layer_kernel<0>: the median "
-                     "is a hidden layer" % tag,
+                     "dispatches of each kernel; layer 0 (48 -> 1024) and the hidden layers share nifg16_layer_kernel<0, 0>: the median "
+                     "is a hidden layer; nifg16_layer_kernel<1, 0> is the last hidden layer with the head fused" % tag,
            "units": "FETCH_SIZE/WRITE_SIZE in KiB; gfx950 correction: read bytes = 2 x FETCH_SIZE x 1024",
            "plain_run": open(os.path.join(src, "plain.log")).read().strip().splitlines()[-1]}
     for kern in sorted(set(fetch) | set(write) | set(mfma)):
@@ -67,7 +71,7 @@ def main():
         for name, ns in avg_ns.items():
             if name.split("(")[0].replace("void ", "").replace("ptd::", "") == short:
                 e["avg_launch_us_kernel_trace"] = ns / 1e3     # average over ALL dispatches, short ones included
-                if "hbm_bytes_per_launch_corrected" in e and short.startswith("nifg_head"):
+                if "hbm_bytes_per_launch_corrected" in e and short.startswith(("nifg_head", "nifg16_finish")):
                     e["hbm_TBps"] = e["hbm_bytes_per_launch_corrected"] / (ns * 1e-9) / 1e12
         if kern in mfma and "SQ_VALU_MFMA_BUSY_CYCLES" in mfma[kern]:
             m = {c: median_of_full(v) for c, v in mfma[kern].items()}

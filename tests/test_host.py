@@ -325,7 +325,7 @@ def test_interactive_restart_and_nif_hot_reload_over_the_ui_port(host, tmp_path)
     port = s.getsockname()[1]
     s.close()
     out = tmp_path / "ui.png"
-    proc = subprocess.Popen([exe, "--assets", str(assets), "-w", str(W), "-h", str(H), "-s", "4000", "--samples-per-step", "20",
+    proc = subprocess.Popen([exe, "--assets", str(assets), "-w", str(W), "-h", str(H), "-s", "4000000", "--samples-per-step", "20",
                              "--interactive-samples", "2", "--max-path-length", "5", "-o", str(out), "--save-interval", "3",
                              "--ui-port", str(port), "--log-level", "debug"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     conn = None
@@ -383,7 +383,7 @@ def test_interactive_restart_and_nif_hot_reload_over_the_ui_port(host, tmp_path)
     log, _ = proc.communicate(timeout=60)
     assert proc.returncode == 0, log[-3000:]
     assert "Rendering stopped by remote UI" in log and "Loading NIF: %s" % other in log
-    assert log.count("Completed render step 1/200") >= 3                                         # first run + two restarts
+    assert log.count("Completed render step 1/200000") >= 3                                      # first run + two restarts
     assert "Interaction stopped reverting samples per step to: 20" in log
     assert got["hdr_header"] == (W, H, H) and got["preview"] >= 8 and got["rates"] >= 8
     assert os.path.getsize(out) > 500                                                            # the last film is left on disk
@@ -470,7 +470,7 @@ def test_ui_client_cannot_abort_the_render_with_a_bad_value(host, tmp_path):
     port = s.getsockname()[1]
     s.close()
     out = tmp_path / "bad.png"
-    proc = subprocess.Popen([exe, "--assets", str(assets), "-w", "64", "-h", "48", "-s", "100000", "--samples-per-step", "10",
+    proc = subprocess.Popen([exe, "--assets", str(assets), "-w", "64", "-h", "48", "-s", "10000000", "--samples-per-step", "10",
                              "--max-path-length", "4", "-o", str(out), "--ui-port", str(port)],
                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     conn = None
@@ -499,9 +499,11 @@ def test_ui_client_cannot_abort_the_render_with_a_bad_value(host, tmp_path):
     time.sleep(0.5)
     conn.sendall(b"stop\n")
     log, _ = proc.communicate(timeout=60)
+    if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        open(os.path.join(ROOT, "gpurun_out", "ui_bad_value.log"), "w").write(log)
     assert proc.returncode == 0, log[-3000:]
     assert log.count("rejected") >= 9 and "Rendering stopped by remote UI" in log
-    assert log.count("Completed render step 1/10000") >= 2       # first run + the restart for fov 60
+    assert log.count("Completed render step 1/1000000") >= 2     # first run + the restart for fov 60
 
 
 @pytest.mark.gpu
