@@ -174,6 +174,8 @@ def main():
     r = ptmi.Renderer(W, H, max_work_items=max(counts), max_path_length=depth, device=device_index, stream=stream)
     r.init_nif_weights(layers, meta["embedding_dimension"], meta["max"], mean)   # program init_nif_weights
     r.init_render_settings(seed=1, aa_noise_scale=0.3, fov_degrees=90.0, samples_per_step=spp)
+    if redeal:
+        r.tile_costs_enable(partition.TILE, partition.TILE)
     r.setup(work)                                                                 # inputs resident in HBM
     slot = max(counts)
     hdr = torch.empty((slot, 3), dtype=torch.float32, device="cuda")
@@ -254,8 +256,8 @@ def main():
         if last or args.save_interval <= 0:
             return
         if redeal:
-            r.read_results(state["work"])                                     # per-item pathLength of the interval
-            cost = torch.from_numpy(partition.tile_costs(state["work"], W, H))
+            # per-tile path-length sums of the interval, summed on the device: 8 B per 16x16 tile leave it, not the worklist
+            cost = torch.from_numpy(r.tile_costs(W, H).astype(np.float64))
             if not rehearsal:
                 cost = cost.cuda()
             dist.all_reduce(cost, op=dist.ReduceOp.SUM)

@@ -97,7 +97,7 @@ typedef struct pt_stats {
   double accumulate_ms;          /* sum over accumulate launches */
   double total_ms;               /* whole path_trace program        (iter_cycle_count x iterations) */
   uint32_t trace_launches, nif_launches, accumulate_launches;
-  uint32_t reserved;
+  uint32_t first_sample;         /* absolute index of the step's first sample iteration (the RNG is keyed by pixel and this index) */
 } pt_stats;
 
 /* One traced path, for kernel-level parity checks: the information the reference keeps in the
@@ -193,6 +193,21 @@ int pt_comm_info(pt_handle h, int* rank, int* world);
 int pt_comm_set_timeout(pt_handle h, uint32_t milliseconds);
 int pt_comm_abort(pt_handle h);
 int pt_film_accumulate(pt_handle h);
+/* Path-length balancing without the worklist leaving the device.  The reference re-deals work by the pathLength every
+ * step returns per work item (LoadBalancer::allocateWorkByPathLength, LoadBalancer.cpp:141-192), which costs the whole
+ * trace buffer both ways per step; across GPUs the unit of re-dealing is an image tile, so what the balancer needs is
+ * kilobytes: per tile of tile_w x tile_h pixels (row-major grid over width x height) the sum of pathLength of this
+ * handle's work items.  pt_tile_costs_enable starts the bookkeeping (what pt_film_accumulate clears from the
+ * accumulators is folded into the per-tile sums first); pt_tile_costs copies, for all n_tiles = ceil(width / tile_w) x
+ * ceil(height / tile_h) tiles, tracked sums + the current accumulators' pathLength to the host (uint64 each; padding
+ * items, u = v = 65535, belong to no tile).  pt_setup starts the sums afresh. */
+/* pt_film_seed: after a re-deal the film has to follow its pixels.  Sets the resident film of the n = current work
+ * items from host values (BGR float32 [n][3], the running sums pt_gather_hdr(PT_HDR_FILM) returned for those pixels),
+ * so that every pixel's fp32 sum continues in step order whichever handle owns it: a balanced render equals the
+ * unbalanced one bit for bit.  Called after pt_setup (which zeroes the film), at save intervals only. */
+int pt_film_seed(pt_handle h, const float* host_bgr, size_t n);
+int pt_tile_costs_enable(pt_handle h, uint32_t tile_w, uint32_t tile_h);
+int pt_tile_costs(pt_handle h, uint64_t* host_costs, size_t n_tiles);
 int pt_gather_hdr(pt_handle h, int32_t source, size_t slot_items, float* root_host_bgr);
 int pt_export_hdr_device(pt_handle h, void* device_bgr, size_t n);
 /* Clear r,g,b,sampleCount,pathLength on the device worklist

@@ -897,9 +897,30 @@ __global__ void export_hdr_kernel(uint32_t n, Accum A, float* bgr) {
 // Resident film: AccumulatedImage::accumulate (src/AccumulatedImage.cpp:59-74: hdr += (b, g, r) * (1 / sampleCount))
 // followed by LoadBalancer::clearInactiveAccumulators (src/LoadBalancer.cpp:198-213) for one work item, on the device.
 // Same fp32 expressions as the host code (no contraction), so a film kept here equals the host film bit for bit.
-__global__ void film_accumulate_kernel(uint32_t n, Accum A, float* film) {
+// Per-tile path-length bookkeeping for the balancer (pt_tile_costs): tile of a work item, or ~0 for padding items.
+struct TileGrid {
+  uint32_t tile_w, tile_h, tiles_x, n_tiles;   // n_tiles = 0: bookkeeping off
+  unsigned long long* cost;                     // [n_tiles] sums of pathLength
+};
+__device__ __forceinline__ uint32_t tile_of(uint32_t pix, const TileGrid& T) {
+  const uint32_t u = pix & 0xffffu, v = pix >> 16;
+  const uint32_t t = (v / T.tile_h) * T.tiles_x + u / T.tile_w;
+  return (u / T.tile_w < T.tiles_x && t < T.n_tiles) ? t : ~0u;
+}
+__global__ void tile_cost_kernel(uint32_t n, Accum A, TileGrid T) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  const uint32_t len = A.length[i], t = tile_of(A.pix[i], T);
+  if (len && t != ~0u) atomicAdd(&T.cost[t], (unsigned long long)len);
+}
+
+__global__ void film_accumulate_kernel(uint32_t n, Accum A, float* film, TileGrid T) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (T.n_tiles) {   // the path lengths about to be cleared go into the per-tile sums first
+    const uint32_t len = A.length[i], t = tile_of(A.pix[i], T);
+    if (len && t != ~0u) atomicAdd(&T.cost[t], (unsigned long long)len);
+  }
   const uint32_t cnt = (uint16_t)A.count[i];     // the host divides by the uint16 wire field
   if (cnt) {
     const float scale = 1.f / (float)cnt;

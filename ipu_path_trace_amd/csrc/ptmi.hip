@@ -151,6 +151,8 @@ struct pt_context {
   size_t comm_slot_agreed = 0;               // slot_items value every rank of the communicator is known to use
   long long* d_slot_check = nullptr;         // {slot, -slot} for the agreement all-reduce
   float* d_film = nullptr;         // resident film: [capacity][3] BGR, sum over steps of the per-step means
+  ptd::TileGrid tiles{};           // per-tile path-length sums for the balancer (pt_tile_costs_enable), n_tiles = 0: off
+  unsigned long long* d_tile_tmp = nullptr;   // tracked sums + current accumulators, staged for the copy to the host
   uint32_t film_steps = 0;
   float* d_hdr_stage = nullptr;    // this rank's tile: [slot_items][3] mean BGR, zero padded
   size_t hdr_stage_floats = 0;
@@ -1067,6 +1069,7 @@ int pt_destroy(pt_handle h) {
   (void)hipFree(h->d_scratch);
   (void)hipFree(h->d_hdr_stage); (void)hipFree(h->d_hdr_gather); (void)hipFree(h->d_film);
   (void)hipFree(h->d_slot_check);
+  (void)hipFree(h->tiles.cost); (void)hipFree(h->d_tile_tmp);
   if (h->comm) (void)ncclCommDestroy(h->comm);
   for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
   if (h->trace_stream && !h->serial) { (void)hipStreamSynchronize(h->trace_stream); (void)hipStreamDestroy(h->trace_stream); }
@@ -1230,6 +1233,7 @@ int pt_setup(pt_handle h, const pt_trace_record* work, size_t n) {
   h->n_items = (uint32_t)n;
   h->film_steps = 0;
   if (h->d_film) PT_HIP(hipMemsetAsync(h->d_film, 0, (size_t)h->capacity * 12, h->stream));   // a new worklist starts a new film
+  if (h->tiles.n_tiles) PT_HIP(hipMemsetAsync(h->tiles.cost, 0, (size_t)h->tiles.n_tiles * 8, h->stream));   // ... and new per-tile sums
   if (n == 0) return PT_OK;
   static_assert(sizeof(pt_trace_record) == 20 && sizeof(ptd::TraceRecordDev) == 20, "TraceRecord wire format");
   PT_HIP(hipMemcpyAsync(h->d_records, work, n * sizeof(pt_trace_record), hipMemcpyHostToDevice, h->stream));
@@ -1339,6 +1343,7 @@ int pt_path_trace(pt_handle h) {
   PT_HIP(hipSetDevice(h->cfg.device));
   memset(&h->stats, 0, sizeof(h->stats));
   h->stats.nif_flops_per_sample = h->env_const ? 0 : h->nif_flops;
+  h->stats.first_sample = h->sample_cursor;
   const uint32_t n = h->n_items;
   if (n == 0) return PT_OK;
 
@@ -1698,10 +1703,61 @@ int pt_film_accumulate(pt_handle h) {
     PT_HIP(hipMemsetAsync(h->d_film, 0, (size_t)h->capacity * 12, h->stream));
   }
   if (h->n_items) {
-    hipLaunchKernelGGL(ptd::film_accumulate_kernel, dim3((h->n_items + 255) / 256), dim3(256), 0, h->stream, h->n_items, h->acc, h->d_film);
+    hipLaunchKernelGGL(ptd::film_accumulate_kernel, dim3((h->n_items + 255) / 256), dim3(256), 0, h->stream, h->n_items, h->acc, h->d_film, h->tiles);
     PT_HIP(hipGetLastError());
   }
   h->film_steps += 1;
+  return PT_OK;
+}
+
+int pt_film_seed(pt_handle h, const float* host_bgr, size_t n) {
+  if (!h) return PT_ERR_INVALID_ARGUMENT;
+  if (n != h->n_items || (!host_bgr && n)) return fail(h, PT_ERR_INVALID_ARGUMENT, "film seed must cover exactly the current work items");
+  PT_HIP(hipSetDevice(h->cfg.device));
+  if (!h->d_film) {
+    PT_HIP(dev_alloc(&h->d_film, (size_t)h->capacity * 3));
+    PT_HIP(hipMemsetAsync(h->d_film, 0, (size_t)h->capacity * 12, h->stream));
+  }
+  if (n) PT_HIP(hipMemcpyAsync(h->d_film, host_bgr, n * 12, hipMemcpyHostToDevice, h->stream));
+  PT_HIP(hipStreamSynchronize(h->stream));   // host buffer is not touched after return
+  return PT_OK;
+}
+
+int pt_tile_costs_enable(pt_handle h, uint32_t tile_w, uint32_t tile_h) {
+  if (!h) return PT_ERR_INVALID_ARGUMENT;
+  if (tile_w == 0 || tile_h == 0) return fail(h, PT_ERR_INVALID_ARGUMENT, "tile size must be > 0");
+  PT_HIP(hipSetDevice(h->cfg.device));
+  const uint32_t tx = (h->cfg.width + tile_w - 1) / tile_w, ty = (h->cfg.height + tile_h - 1) / tile_h;
+  const uint32_t n = tx * ty;
+  PT_HIP(hipStreamSynchronize(h->stream));
+  if (h->tiles.cost) PT_HIP(hipFree(h->tiles.cost));
+  if (h->d_tile_tmp) PT_HIP(hipFree(h->d_tile_tmp));
+  h->tiles = ptd::TileGrid{};
+  h->d_tile_tmp = nullptr;
+  unsigned long long* cost = nullptr;
+  PT_HIP(dev_alloc(&cost, n));
+  PT_HIP(dev_alloc(&h->d_tile_tmp, n));
+  PT_HIP(hipMemsetAsync(cost, 0, (size_t)n * 8, h->stream));
+  h->tiles.tile_w = tile_w; h->tiles.tile_h = tile_h; h->tiles.tiles_x = tx; h->tiles.n_tiles = n; h->tiles.cost = cost;
+  return PT_OK;
+}
+
+int pt_tile_costs(pt_handle h, uint64_t* host_costs, size_t n_tiles) {
+  if (!h) return PT_ERR_INVALID_ARGUMENT;
+  if (!h->tiles.n_tiles) return fail(h, PT_ERR_NOT_READY, "pt_tile_costs_enable has not been called");
+  if (!host_costs || n_tiles != h->tiles.n_tiles)
+    return fail(h, PT_ERR_INVALID_ARGUMENT, "n_tiles must equal the tile grid's size (" + std::to_string(h->tiles.n_tiles) + ")");
+  PT_HIP(hipSetDevice(h->cfg.device));
+  static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "tile costs are 64-bit");
+  PT_HIP(hipMemcpyAsync(h->d_tile_tmp, h->tiles.cost, n_tiles * 8, hipMemcpyDeviceToDevice, h->stream));
+  if (h->n_items) {
+    ptd::TileGrid T = h->tiles;
+    T.cost = h->d_tile_tmp;
+    hipLaunchKernelGGL(ptd::tile_cost_kernel, dim3((h->n_items + 255) / 256), dim3(256), 0, h->stream, h->n_items, h->acc, T);
+    PT_HIP(hipGetLastError());
+  }
+  PT_HIP(hipMemcpyAsync(host_costs, h->d_tile_tmp, n_tiles * 8, hipMemcpyDeviceToHost, h->stream));
+  PT_HIP(hipStreamSynchronize(h->stream));   // host buffer is not touched after return
   return PT_OK;
 }
 

@@ -98,6 +98,37 @@ void LoadBalancer::allocateWorkByPathLength(const IpuJobList& jobs) {
       if (out < list.size()) list[out++] = item;
 }
 
+std::vector<std::int32_t> dealTilesByPathLength(const std::vector<std::uint64_t>& cost, std::size_t devices) {
+  if (devices == 0) throw std::logic_error("dealTilesByPathLength needs at least one device.");
+  std::vector<std::size_t> order(cost.size());
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](std::size_t a, std::size_t b) { return cost[a] > cost[b]; });
+  std::vector<std::int32_t> owner(cost.size());
+  for (std::size_t pos = 0; pos < order.size(); ++pos) {
+    const std::size_t round = pos / devices, idx = pos % devices;
+    owner[order[pos]] = static_cast<std::int32_t>(round % 2 == 0 ? idx : devices - 1 - idx);
+  }
+  return owner;
+}
+
+RecordList tileWorkList(std::size_t imageWidth, std::size_t imageHeight, const std::vector<std::int32_t>& owner,
+                        std::int32_t device, std::size_t padTo) {
+  const std::size_t tx = (imageWidth + kBalanceTile - 1) / kBalanceTile;
+  RecordList items;
+  items.reserve(padTo);
+  for (std::size_t t = 0; t < owner.size(); ++t) {
+    if (owner[t] != device) continue;
+    const std::size_t r0 = (t / tx) * kBalanceTile, c0 = (t % tx) * kBalanceTile;
+    for (std::size_t dy = 0; dy < kBalanceTile; ++dy)
+      for (std::size_t dx = 0; dx < kBalanceTile; ++dx)
+        if (r0 + dy < imageHeight && c0 + dx < imageWidth)
+          items.emplace_back(static_cast<std::uint16_t>(c0 + dx), static_cast<std::uint16_t>(r0 + dy));
+  }
+  if (items.size() > padTo) throw std::logic_error("tileWorkList: the deal does not fit the device's capacity.");
+  items.resize(padTo, TraceRecord(kPaddingCoord, kPaddingCoord));
+  return items;
+}
+
 std::size_t LoadBalancer::clearInactiveAccumulators() { return resetAndSumPathLengths(work.inactive()); }
 
 void LoadBalancer::clearActiveAccumulators() { (void)resetAndSumPathLengths(work.active()); }

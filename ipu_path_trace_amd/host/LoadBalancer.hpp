@@ -3,6 +3,7 @@
 // returns the ray count.  poplar::Target is replaced by DeviceGeometry (IpuPathTraceJob.hpp).
 #pragma once
 #include <cstddef>
+#include <cstdint>
 #include <stdexcept>
 #include <utility>
 #include <vector>
@@ -41,6 +42,24 @@ public:
 private:
   RecordList lists[2];
 };
+
+// ---- path-length balancing ACROSS devices, on image tiles (the unit of re-dealing between GPUs).  The reference pairs
+// the shortest with the longest path inside every IPU tile (allocateWorkByPathLength, LoadBalancer.cpp:141-192); the
+// same idea for D devices: sort the image tiles by measured cost and deal them in boustrophedon order (0..D-1, D-1..0,
+// ...), which for two tiles per device IS the shortest+longest pairing.  Deterministic (stable sort, ties by tile id).
+constexpr std::size_t kBalanceTile = 16;
+inline std::size_t balanceTileCount(std::size_t w, std::size_t h) {
+  return ((w + kBalanceTile - 1) / kBalanceTile) * ((h + kBalanceTile - 1) / kBalanceTile);
+}
+/// owner[t] = device of tile t.
+std::vector<std::int32_t> dealTilesByPathLength(const std::vector<std::uint64_t>& cost, std::size_t devices);
+/// Work items of `device` under `owner`: its tiles in tile order, pixels row-major inside a tile, padded to `padTo`.
+RecordList tileWorkList(std::size_t imageWidth, std::size_t imageHeight, const std::vector<std::int32_t>& owner,
+                        std::int32_t device, std::size_t padTo);
+/// Capacity that fits any deal with equal tile counts (+-1).
+inline std::size_t maxTileItemsPerDevice(std::size_t w, std::size_t h, std::size_t devices) {
+  return (balanceTileCount(w, h) + devices - 1) / devices * kBalanceTile * kBalanceTile;
+}
 
 class LoadBalancer {
 public:

@@ -3,7 +3,9 @@
 #include <atomic>
 #include <cmath>
 #include <cstdio>
+#include <algorithm>
 #include <fstream>
+#include <limits>
 #include <stdexcept>
 #include <thread>
 
@@ -140,7 +142,11 @@ void PathTracerApp::attach() {
     cfg.aa_noise_type = aaNoiseType(args.str("aa-noise-type"));
     cfg.sample_precision = PT_SAMPLES_HALF;
     cfg.device = (std::int32_t)d;
-    cfg.max_work_items = (std::uint32_t)itemsPerDevice;
+    // with load balancing on the resident film the devices trade image tiles: room for any deal with equal tile counts
+    deviceCapacity = itemsPerDevice;
+    if (args.flag("enable-load-balancing"))
+      deviceCapacity = std::max(deviceCapacity, maxTileItemsPerDevice(imageWidth, imageHeight, numDevices));
+    cfg.max_work_items = (std::uint32_t)deviceCapacity;
     pt_handle h = nullptr;
     if (pt_create(&cfg, &h)) throw std::runtime_error(std::string("Could not attach to device: ") + pt_last_error(nullptr));
     devices.push_back(h);
@@ -216,9 +222,10 @@ void PathTracerApp::execute() {
   initialiseState(imageWidth, imageHeight);
 
   pt_log::info_("Render started");
-  // The balancer re-deals the worklist from the path lengths every step returns, so it needs the records on the host
-  // each step (the reference's flow).  Without it nothing but the film ever has to leave the devices.
-  if (args.flag("enable-load-balancing") || args.flag("host-film") || args.u32("ui-port") != 0) executeHostFilm(steps);
+  // Nothing but the film ever has to leave the devices -- load balancing included: the balancer gets per-tile path-length
+  // sums (kilobytes, pt_tile_costs) at the save intervals instead of the whole trace buffer every step.  The reference's
+  // own loop (worklist to the host and back every step, per-item balancing) remains as --host-film, and serves the UI.
+  if (args.flag("host-film") || args.u32("ui-port") != 0) executeHostFilm(steps);
   else executeResidentFilm(steps);
 
   auto endTime = std::chrono::steady_clock::now();
@@ -268,18 +275,31 @@ void PathTracerApp::executeResidentFilm(std::uint32_t steps) {
   const float configExposure = args.f32("exposure"), configGamma = args.f32("gamma");
   const auto fileName = args.str("outfile");
   const auto saveInterval = args.u32("save-interval");
+  const bool loadBalanceEnabled = args.flag("enable-load-balancing");
+  pt_log::info_("Step loop: film resident on the device{}", devices.size() > 1 ? "s" : "");
 
-  // program setup, once: the worklist (pixel coordinates, zero accumulators) goes to the devices and stays there
-  auto& work = traceState->work.getWork().active();
+  // program setup, once: every device gets its slice of the (shuffled) worklist -- pixel coordinates, zero accumulators --
+  // and keeps it; with load balancing the slices are re-dealt at the save intervals (below)
+  const auto& work = traceState->work.getWork().active();
   const std::size_t itemsPerDevice = work.size() / devices.size();
-  std::vector<float> tiles(work.size() * 3);   // rank 0 receives [device][itemsPerDevice][3] BGR film sums
-  RecordList filmRecords;                      // the gathered film as records AccumulatedImage::accumulate takes
-  // Declared AFTER everything its job reads (tiles, filmRecords): if the step loop throws, unwinding destroys -- and so
-  // joins -- the task first, while those buffers are still alive.
+  const std::size_t slot = deviceCapacity;      // items per device incl. padding: equal on all devices (the gather's slot)
+  const TraceRecord padding(std::numeric_limits<std::uint16_t>::max(), std::numeric_limits<std::uint16_t>::max());
+  std::vector<RecordList> deviceWork(devices.size());
+  for (std::size_t d = 0; d < devices.size(); ++d) {
+    deviceWork[d].assign(work.begin() + d * itemsPerDevice, work.begin() + (d + 1) * itemsPerDevice);
+    deviceWork[d].resize(slot, padding);
+  }
+  std::vector<float> tiles(devices.size() * slot * 3);   // rank 0 receives [device][slot][3] BGR film sums
+  RecordList filmRecords;                                 // the gathered film as records AccumulatedImage::accumulate takes
+  // Declared AFTER everything its job reads (filmRecords): if the step loop throws, unwinding destroys -- and so joins --
+  // the task first, while those buffers are still alive.
   AsyncTask hostProcessing;
   onEveryDevice("setup", [&](std::size_t d) {
-    return pt_setup(devices[d], reinterpret_cast<const pt_trace_record*>(work.data() + d * itemsPerDevice), itemsPerDevice);
+    return pt_setup(devices[d], reinterpret_cast<const pt_trace_record*>(deviceWork[d].data()), slot);
   });
+  const std::size_t nTiles = balanceTileCount(imageWidth, imageHeight);
+  if (loadBalanceEnabled)
+    onEveryDevice("tile costs", [&](std::size_t d) { return pt_tile_costs_enable(devices[d], kBalanceTile, kBalanceTile); });
 
   for (auto step = 1u; step <= steps; ++step) {
     auto loopStartTime = std::chrono::steady_clock::now();
@@ -296,18 +316,56 @@ void PathTracerApp::executeResidentFilm(std::uint32_t steps) {
     pt_log::debug_("Total ms per step: {}", stats[0].total_ms);
 
     if (step % saveInterval == 0 || step == steps) {
-      hostProcessing.waitForCompletion();   // the previous save still reads `tiles`
+      hostProcessing.waitForCompletion();   // the previous save still reads filmRecords
       // the ONE exchange of the multi-GPU path: HDR tiles to device 0 over RCCL, then to the host film
       onEveryDevice("HDR gather", [&](std::size_t d) {
-        return pt_gather_hdr(devices[d], PT_HDR_FILM, itemsPerDevice, d == 0 ? tiles.data() : nullptr);
+        return pt_gather_hdr(devices[d], PT_HDR_FILM, slot, d == 0 ? tiles.data() : nullptr);
       });
-      hostProcessing.run([&, step]() {
-        filmRecords = work;
-        for (std::size_t i = 0; i < filmRecords.size(); ++i) {
-          auto& r = filmRecords[i];
-          r.b = tiles[3 * i + 0]; r.g = tiles[3 * i + 1]; r.r = tiles[3 * i + 2];
+      filmRecords.clear();
+      filmRecords.reserve(devices.size() * slot);
+      for (std::size_t d = 0; d < devices.size(); ++d)
+        for (std::size_t i = 0; i < slot; ++i) {
+          TraceRecord r = deviceWork[d][i];
+          const float* t = &tiles[(d * slot + i) * 3];
+          r.b = t[0]; r.g = t[1]; r.r = t[2];
           r.sampleCount = 1;                  // accumulate() multiplies by 1 / sampleCount: the sums pass through
+          filmRecords.push_back(r);
         }
+      if (loadBalanceEnabled && step != steps) {
+        // N3 without the worklist leaving the devices (LoadBalancer::allocateWorkByPathLength, LoadBalancer.cpp:141-192):
+        // per-tile path-length sums from every device, tiles re-dealt by cost, and the film follows its pixels
+        // (pt_film_seed), so every pixel's fp32 sum continues in step order: the image is bit-identical to the unbalanced one.
+        pt_log::info_("Load balancing started ({} image tiles over {} device{})", nTiles, devices.size(), devices.size() > 1 ? "s" : "");
+        std::vector<std::vector<std::uint64_t>> part(devices.size(), std::vector<std::uint64_t>(nTiles));
+        onEveryDevice("tile costs", [&](std::size_t d) { return pt_tile_costs(devices[d], part[d].data(), nTiles); });
+        std::vector<std::uint64_t> cost(nTiles, 0);
+        for (auto& p : part) for (std::size_t t = 0; t < nTiles; ++t) cost[t] += p[t];
+        pt_log::debug_("Load balancing: {} bytes of tile costs from each device (the trace buffer is {} bytes)", nTiles * sizeof(std::uint64_t),
+                       slot * sizeof(TraceRecord));
+        const auto owner = dealTilesByPathLength(cost, devices.size());
+        std::vector<float> running((std::size_t)imageWidth * imageHeight * 3, 0.f);   // the film so far, by pixel
+        for (const auto& r : filmRecords)
+          if (r.u < imageWidth && r.v < imageHeight) {
+            float* p = &running[((std::size_t)r.v * imageWidth + r.u) * 3];
+            p[0] = r.b; p[1] = r.g; p[2] = r.r;
+          }
+        std::vector<std::vector<float>> seed(devices.size());
+        for (std::size_t d = 0; d < devices.size(); ++d) {
+          deviceWork[d] = tileWorkList(imageWidth, imageHeight, owner, (std::int32_t)d, slot);
+          seed[d].assign(slot * 3, 0.f);
+          for (std::size_t i = 0; i < slot; ++i) {
+            const auto& r = deviceWork[d][i];
+            if (r.u < imageWidth && r.v < imageHeight)
+              std::copy_n(&running[((std::size_t)r.v * imageWidth + r.u) * 3], 3, &seed[d][i * 3]);
+          }
+        }
+        onEveryDevice("re-deal", [&](std::size_t d) {
+          return pt_setup(devices[d], reinterpret_cast<const pt_trace_record*>(deviceWork[d].data()), slot) ||
+                 pt_film_seed(devices[d], seed[d].data(), slot);
+        });
+        pt_log::info_("Load balancing finished");
+      }
+      hostProcessing.run([&, step]() {
         traceState->film.reset();
         traceState->film.accumulate(filmRecords);
         traceState->film.saveImages(fileName, step, configExposure, configGamma);   // hdr / step, as ever
@@ -351,6 +409,7 @@ void PathTracerApp::executeHostFilm(std::uint32_t steps) {
   // Declared AFTER the server, the state and the counter its job uses: if anything in the loop throws, unwinding joins
   // the task (its destructor) before the InterfaceServer it talks to is destroyed.
   AsyncTask hostProcessing;
+  pt_log::info_("Step loop: the reference's (worklist to the host and back every step, host film)");
   constexpr std::size_t sampleCountReversionStep = 5;
   std::uint32_t lastStep = 0;   // steps accumulated into the current film
   auto sendRenderSettings = [&]() {   // program init_render_settings (PathTracerApp.cpp:678-686)
@@ -405,7 +464,7 @@ void PathTracerApp::executeHostFilm(std::uint32_t steps) {
     pt_log::debug_("Path-Trace ms: {}", stats[0].path_trace_ms);
     pt_log::debug_("NIF ms: {}", stats[0].nif_ms);
     pt_log::debug_("Total ms per step: {}", stats[0].total_ms);
-    pt_log::debug_("Step {} took {} samples per pixel", step, stats[0].paths / itemsPerDevice);
+    pt_log::debug_("Step {} took {} samples per pixel from sample index {}", step, stats[0].paths / itemsPerDevice, stats[0].first_sample);
 
     const auto deviceDone = std::chrono::steady_clock::now();
     hostProcessing.waitForCompletion();    // join the previous async task before swapping (:703-708)

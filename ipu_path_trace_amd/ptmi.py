@@ -23,7 +23,7 @@ EXPORTS = ["pt_abi_version", "pt_create", "pt_destroy", "pt_last_error", "pt_upl
            "pt_set_render_settings", "pt_setup", "pt_path_trace", "pt_read_results", "pt_get_stats",
            "pt_export_hdr_device", "pt_clear_accumulators", "pt_synchronize", "pt_nif_infer", "pt_trace_paths",
            "pt_comm_get_unique_id", "pt_comm_init_rank", "pt_comm_init_all", "pt_comm_info", "pt_comm_set_timeout", "pt_comm_abort",
-           "pt_gather_hdr", "pt_film_accumulate"]
+           "pt_gather_hdr", "pt_film_accumulate", "pt_tile_costs_enable", "pt_tile_costs", "pt_film_seed"]
 COMM_ID_BYTES = 128
 HDR_ACCUMULATORS, HDR_FILM = 0, 1
 
@@ -53,10 +53,10 @@ class Stats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("segments", C.c_uint64), ("escaped", C.c_uint64),
                 ("nif_flops_per_sample", C.c_uint64), ("path_trace_ms", C.c_double), ("nif_ms", C.c_double),
                 ("accumulate_ms", C.c_double), ("total_ms", C.c_double), ("trace_launches", C.c_uint32),
-                ("nif_launches", C.c_uint32), ("accumulate_launches", C.c_uint32), ("reserved", C.c_uint32)]
+                ("nif_launches", C.c_uint32), ("accumulate_launches", C.c_uint32), ("first_sample", C.c_uint32)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        return {k: getattr(self, k) for k, _ in self._fields_}
 
 
 _libs = {}
@@ -100,6 +100,9 @@ def load_library(diag=False):
     L.pt_comm_abort.argtypes = [C.c_void_p]
     L.pt_gather_hdr.argtypes = [C.c_void_p, C.c_int32, C.c_size_t, C.c_void_p]
     L.pt_film_accumulate.argtypes = [C.c_void_p]
+    L.pt_film_seed.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.pt_tile_costs_enable.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+    L.pt_tile_costs.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.pt_clear_accumulators.argtypes = [C.c_void_p]
     L.pt_synchronize.argtypes = [C.c_void_p]
     L.pt_nif_infer.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
@@ -236,6 +239,24 @@ class Renderer:
     def film_accumulate(self):
         """AccumulatedImage::accumulate + clearInactiveAccumulators on the device (the film stays resident)."""
         self._check(self._lib.pt_film_accumulate(self.handle))
+
+    def film_seed(self, bgr):
+        """Set the resident film of the current work items (float32 [n, 3] BGR running sums): the film follows its pixels."""
+        bgr = np.ascontiguousarray(bgr, dtype=np.float32)
+        self._check(self._lib.pt_film_seed(self.handle, bgr.ctypes.data, bgr.shape[0]))
+
+    def tile_costs_enable(self, tile_w, tile_h):
+        """Keep per-tile sums of pathLength on the device (what the path-length balancer needs: kilobytes, not the worklist)."""
+        self._tile_grid = (tile_w, tile_h)
+        self._check(self._lib.pt_tile_costs_enable(self.handle, tile_w, tile_h))
+
+    def tile_costs(self, width, height):
+        """uint64 [tiles]: per-tile sum of pathLength since the last setup (row-major grid of the enabled tile size)."""
+        tw, th = self._tile_grid
+        n = ((width + tw - 1) // tw) * ((height + th - 1) // th)
+        out = np.zeros(n, dtype=np.uint64)
+        self._check(self._lib.pt_tile_costs(self.handle, out.ctypes.data, n))
+        return out
 
     def gather_hdr(self, slot_items, source=HDR_ACCUMULATORS):
         """One RCCL gather of HDR tiles to rank 0.  Returns float32 [world, slot_items, 3] (BGR) on rank 0, None elsewhere."""

@@ -196,14 +196,23 @@ def test_redeal_by_measured_path_length_keeps_the_film(ptmi_lib):
             r = ptmi_lib.Renderer(W, H, max_work_items=partition.max_items_per_rank(W, H, world), max_path_length=8)
             r.init_nif_weights(L, 12, nif_assets.URBAN_ALLEY_META["max"], mean)
             r.init_render_settings(samples_per_step=spp)
+            r.tile_costs_enable(partition.TILE, partition.TILE)
             r.setup(work)
             for _ in range(first_sample_step):            # advance the sample sequence to the interval's first index
                 r.path_trace()
                 r.clear_accumulators()
             r.path_trace()
             tiles.append(r.gather_hdr(partition.max_items_per_rank(W, H, world))[0])
+            on_device = r.tile_costs(W, H)                # N3 without the worklist leaving the device: 8 B per tile
             r.read_results(work)
-            cost += partition.tile_costs(work, W, H)
+            np.testing.assert_array_equal(on_device, partition.tile_costs(work, W, H).astype(np.uint64))
+            assert on_device.nbytes * 50 < work.nbytes
+            cost += on_device
+            # what pt_film_accumulate clears from the accumulators is folded into the per-tile sums first
+            r.film_accumulate()
+            r.read_results(work)
+            assert not work["pathLength"].any()
+            np.testing.assert_array_equal(r.tile_costs(W, H), on_device)
             r.close()
         return partition.assemble_hdr(W, H, world, tiles, owner=owner), cost
 

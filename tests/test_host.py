@@ -266,7 +266,7 @@ def _run_cli(host, tmp_path, name, extra, W=96, H=80, spp=4, steps=3):
         nif_assets.write_ptnif(str(assets / "converted.ptnif"), nif_assets.synthetic_nif(), 12)
     out = tmp_path / (name + ".png")
     r = subprocess.run([exe, "--assets", str(assets), "-w", str(W), "-h", str(H), "-s", str(spp * steps),
-                        "--samples-per-step", str(spp), "--max-path-length", "7", "-o", str(out), "--save-interval", "2"] + extra,
+                        "--samples-per-step", str(spp), "--max-path-length", "7", "-o", str(out), "--save-interval", "2"] + extra,   # (a later --save-interval in `extra` wins)
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     film = np.zeros((H, W, 3), dtype=np.float32)
@@ -277,22 +277,37 @@ def _run_cli(host, tmp_path, name, extra, W=96, H=80, spp=4, steps=3):
 
 @pytest.mark.gpu
 def test_cli_resident_film_host_film_and_load_balancing_give_the_same_film(host, oracle, tmp_path):
-    """SURVEY.md rows A17/A18/N3 on the GPU.  Three step loops over the same render:
+    """SURVEY.md rows A17/A18/N3 on the GPU.  Four step loops over the same render:
     * default: film resident on the device (pt_film_accumulate), one pt_gather_hdr per save interval;
     * --host-film: the reference's loop (setup -> path_trace -> read_results every step, host film);
-    * --enable-load-balancing: the reference's loop + LoadBalancer::allocateWorkByPathLength from step 2 on
+    * --enable-load-balancing: STILL the resident film -- per-tile path-length sums (pt_tile_costs: kilobytes) leave the
+      device at the save intervals, image tiles are re-dealt by cost and the film follows its pixels (pt_film_seed);
+    * --host-film --enable-load-balancing: the reference's loop + LoadBalancer::allocateWorkByPathLength from step 2 on
       (LoadBalancer.cpp:141-192).
-    The RNG is keyed by pixel and absolute sample index and the film arithmetic is the same fp32 expressions, so all
-    three films are bit-identical, and they match the oracle within the NIF tolerance."""
+    The RNG is keyed by pixel and absolute sample index and the film arithmetic is the same fp32 expressions in the same
+    order, so all four films are bit-identical -- also over several re-deals -- and they match the oracle within the NIF
+    tolerance."""
+    import re
     O = oracle
     W, H, spp, steps = 96, 80, 4, 3
     resident, log = _run_cli(host, tmp_path, "resident", [])
     assert "Saved images at step 2" in log and "Saved images at step 3" in log and "Completed render step 3/3" in log
-    hostfilm, _ = _run_cli(host, tmp_path, "hostfilm", ["--host-film"])
-    balanced, log = _run_cli(host, tmp_path, "balanced", ["--enable-load-balancing"])
-    assert "Load balancing finished" in log
+    assert "Step loop: film resident on the device" in log
+    hostfilm, log = _run_cli(host, tmp_path, "hostfilm", ["--host-film"])
+    assert "Step loop: the reference's" in log
+    balanced, log = _run_cli(host, tmp_path, "balanced", ["--enable-load-balancing", "--log-level", "debug"])
+    assert "Load balancing finished" in log and "Step loop: film resident on the device" in log
+    shipped, trace_buffer = map(int, re.search(r"Load balancing: (\d+) bytes of tile costs from each device \(the trace buffer is (\d+) bytes\)", log).groups())
+    assert shipped == 30 * 8 and shipped * 100 < trace_buffer          # 6 x 5 tiles of 16 x 16: 240 B against 153,600 B
+    refbal, log = _run_cli(host, tmp_path, "refbal", ["--host-film", "--enable-load-balancing"])
+    assert "Load balancing finished" in log and "Step loop: the reference's" in log
     assert resident.tobytes() == hostfilm.tobytes()
     assert balanced.tobytes() == hostfilm.tobytes()
+    assert refbal.tobytes() == hostfilm.tobytes()
+    # several re-deals (save interval 1, 5 steps): every pixel's sum continues in step order through the seeds
+    many, log = _run_cli(host, tmp_path, "many", ["--enable-load-balancing", "--save-interval", "1"], steps=5)
+    plain, _ = _run_cli(host, tmp_path, "plain5", [], steps=5)
+    assert log.count("Load balancing finished") == 4 and many.tobytes() == plain.tobytes()
     cfg = O.make_config(width=W, height=H, max_path_length=7, env_mode=O.ENV_NIF)
     ref = O.worklist(W, H)
     O.render(cfg, O.Nif(nif_assets.synthetic_nif(), 12, nif_assets.URBAN_ALLEY_META["max"], nif_assets.folded_mean()), ref, 0, spp * steps)
@@ -390,6 +405,99 @@ def test_interactive_restart_and_nif_hot_reload_over_the_ui_port(host, tmp_path)
 
 
 @pytest.mark.gpu
+def test_film_after_a_nif_hot_reload_matches_the_oracle(host, oracle, tmp_path):
+    """SURVEY.md row N4, the film itself (PathTracerApp.cpp:548-557: load_nif -> loadNifModels -> init_nif_weights again, and
+    the render restarts at step 1 with a fresh film).  A client swaps the NIF for another one (seed 99) in the middle of a
+    render and stops it a few steps later; the image left on disk must be the oracle's render WITH THE NEW NIF over exactly
+    the sample indices the restarted render took (the sample sequence of a handle runs on through a restart; every step
+    logs its first index).  --interactive-samples == --samples-per-step, so every step takes the same count."""
+    import re
+    import socket
+    import threading
+    import time
+    O = oracle
+    exe = os.path.join(HOST, "ipu_trace")
+    assets = tmp_path / "assets.extra"
+    assets.mkdir()
+    nif_assets.write_metadata(str(assets / "nif_metadata.txt"))
+    nif_assets.write_ptnif(str(assets / "converted.ptnif"), nif_assets.synthetic_nif(), 12)
+    other = tmp_path / "other.extra"
+    other.mkdir()
+    nif_assets.write_metadata(str(other / "nif_metadata.txt"))
+    new_nif = nif_assets.synthetic_nif(seed=99)
+    nif_assets.write_ptnif(str(other / "converted.ptnif"), new_nif, 12)
+    W, H, S, depth = 64, 48, 6, 5
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = tmp_path / "reload.png"
+    proc = subprocess.Popen([exe, "--assets", str(assets), "-w", str(W), "-h", str(H), "-s", str(S * 1000000), "--samples-per-step", str(S),
+                             "--interactive-samples", str(S), "--max-path-length", str(depth), "-o", str(out), "--save-interval", "1000",
+                             "--ui-port", str(port), "--log-level", "debug"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    conn = None
+    for _ in range(600):
+        try:
+            conn = socket.create_connection(("127.0.0.1", port), timeout=1.0)
+            break
+        except OSError:
+            time.sleep(0.1)
+    assert conn is not None, "ui server never came up"
+    progress = []
+
+    def reader():
+        f = conn.makefile("rb")
+        while True:
+            line = f.readline()
+            if not line:
+                return
+            t = line.decode().split()
+            if t[0] == "progress":
+                progress.append(float(t[1]))
+            elif t[0] == "render_preview":
+                f.read(int(t[3]))
+            elif t[0] == "hdr_packet":
+                f.read(int(t[2]))
+
+    threading.Thread(target=reader, daemon=True).start()
+
+    def wait_for(cond, what, seconds=60):
+        t0 = time.time()
+        while not cond():
+            assert time.time() - t0 < seconds and proc.poll() is None, what
+            time.sleep(0.005)
+
+    wait_for(lambda: len(progress) >= 4, "no progress from the first render")
+    conn.sendall(("load_nif %s\n" % other).encode())
+    n = len(progress)
+    wait_for(lambda: any(b < a for a, b in zip(progress[n - 1:], progress[n:])), "no restart after load_nif")
+    m = len(progress)
+    wait_for(lambda: len(progress) >= m + 6, "the restarted render does not advance")
+    conn.sendall(b"stop\n")
+    log, _ = proc.communicate(timeout=120)
+    assert proc.returncode == 0, log[-3000:]
+    assert "Loading NIF: %s" % other in log and "Rendering stopped by remote UI" in log
+    last = int(re.findall(r"Saved images at step (\d+)", log)[-1])
+    tail = log[log.rindex("Step 1 took", 0, log.rindex("Completed render step 1/")):]   # from step 1 of the LAST render on
+    firsts = {int(a): int(c) for a, b, c in re.findall(r"Step (\d+) took (\d+) samples per pixel from sample index (\d+)", tail)}
+    assert last >= 6 and all(firsts[k] == firsts[1] + (k - 1) * S for k in range(1, last + 1)), (last, firsts)
+    assert firsts[1] >= 4 * S                                    # the first render's steps came before
+    film = np.zeros((H, W, 3), dtype=np.float32)
+    ww, hh = C.c_size_t(), C.c_size_t()
+    assert host.pth_read_exr(str(tmp_path / "reload.exr").encode(), film.ctypes.data, film.size, C.byref(ww), C.byref(hh)) == 0
+    cfg = O.make_config(width=W, height=H, max_path_length=depth, env_mode=O.ENV_NIF)
+    ref = O.worklist(W, H)
+    O.render(cfg, O.Nif(new_nif, 12, nif_assets.URBAN_ALLEY_META["max"], nif_assets.folded_mean()), ref, firsts[1], last * S)
+    exp = np.stack([ref["b"], ref["g"], ref["r"]], -1).reshape(H, W, 3) / (last * S)
+    np.testing.assert_allclose(film, exp, rtol=2e-2, atol=1e-6)
+    # and it is NOT the old NIF's image: the swap really took place
+    old = O.worklist(W, H)
+    O.render(cfg, O.Nif(nif_assets.synthetic_nif(), 12, nif_assets.URBAN_ALLEY_META["max"], nif_assets.folded_mean()), old, firsts[1], last * S)
+    old_img = np.stack([old["b"], old["g"], old["r"]], -1).reshape(H, W, 3) / (last * S)
+    assert np.abs(film - old_img).max() > 10 * np.abs(film - exp).max()
+
+
+@pytest.mark.gpu
 def test_restart_then_detach_still_reverts_to_the_full_sample_count(host, tmp_path):
     """PathTracerApp.cpp:656-686: the reversion to --samples-per-step at step 5 and the init_render_settings at steps 1
     and 5 do not depend on a UI server being attached.  A client that changes a setting (restart: the device goes to
@@ -445,7 +553,7 @@ def test_restart_then_detach_still_reverts_to_the_full_sample_count(host, tmp_pa
     assert "Remote UI disconnected." in log
     tail = log[log.rindex("Completed render step 1/%d" % steps):]          # the restarted render
     assert "Remote UI disconnected." in tail, "the client detached before the restart was processed: scenario not reached"
-    took = {int(a): int(b) for a, b in re.findall(r"Step (\d+) took (\d+) samples per pixel", tail)}
+    took = {int(a): int(b) for a, b in re.findall(r"Step (\d+) took (\d+) samples per pixel", tail)}   # (the last occurrence of a step wins)
     gone = tail.index("Remote UI disconnected.")
     revert = tail.index("Interaction stopped reverting samples per step to: %d" % full)
     assert gone < revert, "the detach came after step 5: scenario not reached (steps too fast)"
