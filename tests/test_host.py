@@ -342,7 +342,7 @@ def test_interactive_restart_and_nif_hot_reload_over_the_ui_port(host, tmp_path)
     out = tmp_path / "ui.png"
     proc = subprocess.Popen([exe, "--assets", str(assets), "-w", str(W), "-h", str(H), "-s", "4000000", "--samples-per-step", "20",
                              "--interactive-samples", "2", "--max-path-length", "5", "-o", str(out), "--save-interval", "3",
-                             "--ui-port", str(port), "--log-level", "debug"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+                             "--ui-port", str(port), "--log-level", "debug"], stdout=open(str(tmp_path / "cli.log"), "w"), stderr=subprocess.STDOUT, text=True)
     conn = None
     for _ in range(600):                                   # the server starts listening after the device is attached
         try:
@@ -395,7 +395,10 @@ def test_interactive_restart_and_nif_hot_reload_over_the_ui_port(host, tmp_path)
     time.sleep(0.5)
     wait_for(lambda: got["hdr_header"] is not None and got["hdr_rows"] >= H, "no raw film transfer at the save interval")
     conn.sendall(b"stop\n")
-    log, _ = proc.communicate(timeout=60)
+    proc.wait(timeout=60)
+    log = open(str(tmp_path / "cli.log")).read()   # (a file, not a pipe: an unread pipe fills up and blocks the renderer in its logger)
+    if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        open(os.path.join(ROOT, "gpurun_out", "ui_interactive.log"), "w").write(log + "\nGOT %r\n" % {k: (v if k != "progress" else len(v)) for k, v in got.items()})
     assert proc.returncode == 0, log[-3000:]
     assert "Rendering stopped by remote UI" in log and "Loading NIF: %s" % other in log
     assert log.count("Completed render step 1/200000") >= 3                                      # first run + two restarts
@@ -434,7 +437,7 @@ def test_film_after_a_nif_hot_reload_matches_the_oracle(host, oracle, tmp_path):
     out = tmp_path / "reload.png"
     proc = subprocess.Popen([exe, "--assets", str(assets), "-w", str(W), "-h", str(H), "-s", str(S * 1000000), "--samples-per-step", str(S),
                              "--interactive-samples", str(S), "--max-path-length", str(depth), "-o", str(out), "--save-interval", "1000",
-                             "--ui-port", str(port), "--log-level", "debug"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+                             "--ui-port", str(port), "--log-level", "debug"], stdout=open(str(tmp_path / "cli.log"), "w"), stderr=subprocess.STDOUT, text=True)
     conn = None
     for _ in range(600):
         try:
@@ -474,7 +477,8 @@ def test_film_after_a_nif_hot_reload_matches_the_oracle(host, oracle, tmp_path):
     m = len(progress)
     wait_for(lambda: len(progress) >= m + 6, "the restarted render does not advance")
     conn.sendall(b"stop\n")
-    log, _ = proc.communicate(timeout=120)
+    proc.wait(timeout=120)
+    log = open(str(tmp_path / "cli.log")).read()   # (a file, not a pipe: an unread pipe fills up and blocks the renderer in its logger)
     assert proc.returncode == 0, log[-3000:]
     assert "Loading NIF: %s" % other in log and "Rendering stopped by remote UI" in log
     last = int(re.findall(r"Saved images at step (\d+)", log)[-1])
@@ -519,7 +523,7 @@ def test_restart_then_detach_still_reverts_to_the_full_sample_count(host, tmp_pa
     out = tmp_path / "detach.png"
     proc = subprocess.Popen([exe, "--assets", str(assets), "-w", str(W), "-h", str(H), "-s", str(full * steps), "--samples-per-step", str(full),
                              "--interactive-samples", str(inter), "--max-path-length", "5", "-o", str(out), "--save-interval", "100",
-                             "--ui-port", str(port), "--log-level", "debug"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+                             "--ui-port", str(port), "--log-level", "debug"], stdout=open(str(tmp_path / "cli.log"), "w"), stderr=subprocess.STDOUT, text=True)
     conn = None
     for _ in range(600):
         try:
@@ -548,7 +552,8 @@ def test_restart_then_detach_still_reverts_to_the_full_sample_count(host, tmp_pa
     conn.shutdown(socket.SHUT_RDWR)                            # ... and leave at once: detached around step 2
     f.close()                                                  # (a makefile() object keeps the descriptor open)
     conn.close()
-    log, _ = proc.communicate(timeout=180)
+    proc.wait(timeout=180)
+    log = open(str(tmp_path / "cli.log")).read()   # (a file, not a pipe: an unread pipe fills up and blocks the renderer in its logger)
     assert proc.returncode == 0, log[-3000:]
     assert "Remote UI disconnected." in log
     tail = log[log.rindex("Completed render step 1/%d" % steps):]          # the restarted render
@@ -580,7 +585,7 @@ def test_ui_client_cannot_abort_the_render_with_a_bad_value(host, tmp_path):
     out = tmp_path / "bad.png"
     proc = subprocess.Popen([exe, "--assets", str(assets), "-w", "64", "-h", "48", "-s", "10000000", "--samples-per-step", "10",
                              "--max-path-length", "4", "-o", str(out), "--ui-port", str(port)],
-                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+                            stdout=open(str(tmp_path / "cli.log"), "w"), stderr=subprocess.STDOUT, text=True)
     conn = None
     for _ in range(600):
         try:
@@ -591,13 +596,20 @@ def test_ui_client_cannot_abort_the_render_with_a_bad_value(host, tmp_path):
     assert conn is not None
     import threading
 
+    drained = {"bytes": 0, "end": None}
+
     def drain():                                                 # a client that stops reading would block the server's sends
         try:
-            while conn.recv(65536):
-                pass
-        except OSError:
-            pass
+            while True:
+                d = conn.recv(1 << 20)
+                if not d:
+                    drained["end"] = "eof"
+                    return
+                drained["bytes"] += len(d)
+        except OSError as e:
+            drained["end"] = repr(e)
 
+    conn.settimeout(None)                                        # (create_connection's timeout would end the drain on a quiet second)
     threading.Thread(target=drain, daemon=True).start()
     conn.sendall(b"interactive_samples 0\nfov 0\nfov 200\ninteractive_samples 70000\ninteractive_samples abc\nfov\ngamma 0\n"
                  b"env_rotation nan\ninteractive_samples 2.5\n" + b"x" * 10000 + b"\n")
@@ -606,9 +618,10 @@ def test_ui_client_cannot_abort_the_render_with_a_bad_value(host, tmp_path):
     conn.sendall(b"fov 60\n")                                   # a good value still restarts the render
     time.sleep(0.5)
     conn.sendall(b"stop\n")
-    log, _ = proc.communicate(timeout=60)
+    proc.wait(timeout=60)
+    log = open(str(tmp_path / "cli.log")).read()   # (a file, not a pipe: an unread pipe fills up and blocks the renderer in its logger)
     if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
-        open(os.path.join(ROOT, "gpurun_out", "ui_bad_value.log"), "w").write(log)
+        open(os.path.join(ROOT, "gpurun_out", "ui_bad_value.log"), "w").write(log + "\nDRAINED %r\n" % drained)
     assert proc.returncode == 0, log[-3000:]
     assert log.count("rejected") >= 9 and "Rendering stopped by remote UI" in log
     assert log.count("Completed render step 1/1000000") >= 2     # first run + the restart for fov 60
