@@ -129,6 +129,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void nif_kernel_v4(const Nif
     for (int k = 0; k < PW; ++k) slab_piece(k);
     slab_end();
   }
+  unsigned long long t_cycles = 0, t_real = 0;   // in-kernel clock stamps of workgroup 0 (this kernel exists in the profiling build only)
+  if (blockIdx.x == 0 && threadIdx.x == 0) { t_cycles = __builtin_amdgcn_s_memtime(); t_real = __builtin_amdgcn_s_memrealtime(); }
   uint32_t q = 0;
   int pf_next = PW;
 
@@ -401,6 +403,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void nif_kernel_v4(const Nif
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the run-ahead DMA before the wave ends
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    g_nif_clock[0] = __builtin_amdgcn_s_memtime() - t_cycles;
+    g_nif_clock[1] = __builtin_amdgcn_s_memrealtime() - t_real;
+  }
 }
 
 }  // namespace ptd

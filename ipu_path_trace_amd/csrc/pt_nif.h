@@ -420,7 +420,11 @@ struct NifV3Geometry {
 };
 
 // DIAG (timing-only builds, results invalid): bit 0 = no ring sync / DMA, bit 1 = no LDS reads of A,
-// bit 2 = no epilogue arithmetic, bit 3 = no encode.
+// bit 2 = no epilogue arithmetic, bit 3 = no encode.  Bit 5 (valid results, profiling build): workgroup 0 stamps
+// s_memtime / s_memrealtime around its whole tile loop -> the in-kernel clock (MI355X_MICROARCH.md, DVFS give-back item 6).
+#ifdef PTMI_DIAG_BUILD
+__device__ unsigned long long g_nif_clock[2];   // shader cycles, 100 MHz ticks of the last stamped launch's workgroup 0
+#endif
 template <int H, int E, int WAVES, int TPS, int DIAG = 0>
 __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void nif_kernel_v3(const NifParams P) {
   using G = NifV3Geometry<H, E, WAVES, TPS>;
@@ -512,6 +516,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void nif_kernel_v3(const Nif
   }
   uint32_t q = 0;   // consumer stage
   int pf_next = PW; // next piece of the slab being prefetched during this stage (PW = none pending)
+#ifdef PTMI_DIAG_BUILD
+  unsigned long long t_cycles = 0, t_real = 0;
+  if constexpr ((DIAG & 32) != 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) { t_cycles = __builtin_amdgcn_s_memtime(); t_real = __builtin_amdgcn_s_memrealtime(); }
+  }
+#endif
 
   // Start of a ring stage: my pieces of this stage's slab have landed (the slab after it may still be in
   // flight), everyone's have after the barrier, and the slot read two stages ago is free for the next slab.
@@ -797,6 +807,14 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void nif_kernel_v3(const Nif
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the run-ahead DMA before the wave ends
+#ifdef PTMI_DIAG_BUILD
+  if constexpr ((DIAG & 32) != 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      g_nif_clock[0] = __builtin_amdgcn_s_memtime() - t_cycles;
+      g_nif_clock[1] = __builtin_amdgcn_s_memrealtime() - t_real;
+    }
+  }
+#endif
 }
 
 

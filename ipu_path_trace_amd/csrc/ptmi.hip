@@ -637,6 +637,7 @@ bool launch_nif_diag(pt_handle h, const ptd::NifParams& N, int blocks) {
       case 7: launch_nif_v3<HID, E, 8, 2, 7>(h, N, blocks); return true;
       case 15: launch_nif_v3<HID, E, 8, 2, 15>(h, N, blocks); return true;
       case 16: launch_nif_v3<HID, E, 8, 2, 16>(h, N, blocks); return true;
+      case 32: launch_nif_v3<HID, E, 8, 2, 32>(h, N, blocks); return true;
       default: break;
     }
   }
@@ -1852,6 +1853,16 @@ int pt_gather_hdr(pt_handle h, int32_t source, size_t slot_items, float* root_ho
 int pt_diag_inject_fault(pt_handle h, int32_t batch) {
   if (!h) return PT_ERR_INVALID_ARGUMENT;
   h->diag_fault_batch = batch;
+  return PT_OK;
+}
+
+// profiling build only: in-kernel clock of the last stamped fused-NIF launch (nif_kernel_v3 with DIAG bit 5, nif_kernel_v4):
+// out2[0] = shader cycles, out2[1] = 100 MHz ticks of its workgroup 0
+int pt_diag_nif_clock(pt_handle h, unsigned long long* out2) {
+  if (!h || !out2) return PT_ERR_INVALID_ARGUMENT;
+  PT_HIP(hipSetDevice(h->cfg.device));
+  PT_HIP(hipStreamSynchronize(h->stream));
+  PT_HIP(hipMemcpyFromSymbol(out2, HIP_SYMBOL(ptd::g_nif_clock), 16));
   return PT_OK;
 }
 

@@ -110,6 +110,7 @@ def load_library(diag=False):
     if diag:
         L.pt_diag_inject_fault.argtypes = [C.c_void_p, C.c_int32]
         L.pt_diag_stamps.argtypes = [C.c_void_p, C.c_void_p]
+        L.pt_diag_nif_clock.argtypes = [C.c_void_p, C.c_void_p]
     _libs[diag] = L
     return L
 
