@@ -1,5 +1,8 @@
 #include "Hdf5Reader.hpp"
 
+#include <zlib.h>
+
+#include <algorithm>
 #include <cstring>
 #include <fstream>
 #include <sstream>
@@ -11,6 +14,25 @@ const unsigned char kSignature[8] = {0x89, 'H', 'D', 'F', '\r', '\n', 0x1a, '\n'
 constexpr std::uint64_t kUndefined = ~0ull;
 [[noreturn]] void fail(const std::string& m) { throw std::runtime_error("HDF5 reader: " + m); }
 std::size_t pad8(std::size_t n) { return (n + 7) & ~std::size_t(7); }
+const char* filterName(unsigned id) {
+  switch (id) {
+    case 1: return "deflate (gzip)";
+    case 2: return "shuffle";
+    case 3: return "fletcher32";
+    case 4: return "szip";
+    case 5: return "nbit";
+    case 6: return "scaleoffset";
+    case 307: return "bzip2";
+    case 32000: return "lzf";
+    case 32001: return "blosc";
+    case 32004: return "lz4";
+    case 32008: return "bitshuffle";
+    case 32013: return "zfp";
+    case 32015: return "zstd";
+    case 32026: return "blosc2";
+    default: return "unregistered or third-party";
+  }
+}
 }  // namespace
 
 void File::need(std::size_t off, std::size_t n, const char* what) const {
@@ -229,7 +251,9 @@ std::string File::readStringAttribute(const std::string& objectPath, const std::
 
 Dataset File::openDataSet(const std::string& path) const {
   Dataset out;
-  bool haveSpace = false, haveType = false, haveLayout = false;
+  bool haveSpace = false, haveType = false, haveLayout = false, isChunked = false;
+  ChunkedLayout chunked;
+  std::vector<Filter> filters;
   for (const Message& m : objectMessages(resolve(path))) {
     const std::size_t p = m.offset;
     if (m.type == 0x0001) {   // dataspace
@@ -261,7 +285,13 @@ Dataset File::openDataSet(const std::string& path) const {
           const std::size_t n = u(p + 2, 2);
           need(p + 4, n, "compact dataset data");
           out.bytes.assign(d.begin() + p + 4, d.begin() + p + 4 + n);
-        } else fail("chunked datasets are not supported (" + path + ")");
+        } else if (cls == 2) {   // chunked: dimensionality, chunk B-tree address, chunk dims (the last one is the element size)
+          const int nd = d[p + 2];
+          if (nd < 2 || nd > 9) fail("chunked dataset '" + path + "' has an unsupported dimensionality");
+          chunked.btree = addr(p + 3);
+          for (int i = 0; i < nd; ++i) chunked.dims.push_back((std::size_t)u(p + 3 + sizeOffsets + 4 * i, 4));
+          isChunked = true;
+        } else fail("data layout class " + std::to_string(cls) + " of '" + path + "' is not supported (virtual dataset?)");
       } else if (version == 1 || version == 2) {
         const int rank = d[p + 1], cls = d[p + 2];
         std::size_t q = p + 8;
@@ -280,22 +310,164 @@ Dataset File::openDataSet(const std::string& path) const {
           const std::size_t n = u(q, 4);
           need(q + 4, n, "compact dataset data");
           out.bytes.assign(d.begin() + q + 4, d.begin() + q + 4 + n);
-        } else fail("chunked datasets are not supported (" + path + ")");
-      } else fail("unsupported data layout version");
+        } else if (cls == 2) {
+          if (rank < 2 || rank > 9) fail("chunked dataset '" + path + "' has an unsupported dimensionality");
+          chunked.btree = addr(q);
+          for (int i = 0; i < rank; ++i) chunked.dims.push_back((std::size_t)u(q + sizeOffsets + 4 * i, 4));
+          isChunked = true;
+        } else fail("data layout class " + std::to_string(cls) + " of '" + path + "' is not supported");
+      } else if (version == 4) {
+        fail("version-4 data layout of '" + path + "' (written with libver='latest': v2 B-tree / extensible-array / fixed-array chunk "
+             "index) is not supported -- rewrite the file with the default libver");
+      } else fail("unsupported data layout version " + std::to_string(version));
       haveLayout = true;
-    } else if (m.type == 0x000B) {
-      fail("filtered (compressed) datasets are not supported (" + path + ")");
+    } else if (m.type == 0x000B) {   // filter pipeline (v1: padded names and values; v2: neither, no name below id 256)
+      need(p, 2, "a filter pipeline message");
+      const int version = d[p], count = d[p + 1];
+      if (version != 1 && version != 2) fail("unsupported filter pipeline version " + std::to_string(version));
+      std::size_t q = p + (version == 1 ? 8 : 2);
+      for (int i = 0; i < count; ++i) {
+        need(q, 8, "a filter description");
+        Filter f;
+        f.id = (std::uint16_t)u(q, 2);
+        std::size_t nameLen = 0;
+        if (version == 1 || f.id >= 256) { nameLen = u(q + 2, 2); q += 2; }
+        q += 2;                                   // id (+ name length) consumed
+        const std::size_t nvals = u(q + 2, 2);    // flags at q, number of client values at q + 2
+        q += 4;
+        q += (version == 1) ? pad8(nameLen) : nameLen;
+        need(q, 4 * nvals, "filter client data");
+        for (std::size_t k = 0; k < nvals; ++k) f.values.push_back((std::uint32_t)u(q + 4 * k, 4));
+        q += 4 * nvals;
+        if (version == 1 && (nvals & 1)) q += 4;
+        filters.push_back(std::move(f));
+      }
     }
   }
   if (!haveSpace || !haveType || !haveLayout) fail("'" + path + "' is not a dataset");
   std::size_t n = out.elementSize;
   for (auto s : out.shape) {
-    if (s && n > d.size() / s) fail("dataset '" + path + "' has a shape larger than the file");
+    if (s && n > (std::size_t(1) << 40) / s) fail("dataset '" + path + "' has an implausible shape");
     n *= s;
   }
-  if (out.bytes.size() < n) fail("dataset '" + path + "' holds fewer bytes than its shape needs");
+  for (const Filter& f : filters)
+    if (f.id < 1 || f.id > 3)
+      fail("dataset '" + path + "' uses filter " + std::to_string(f.id) + " (" + filterName(f.id) + "), which this reader cannot undo: "
+           "supported are deflate (1), shuffle (2) and fletcher32 (3)");
+  if (isChunked) {
+    if (n > 64 * d.size() + (std::size_t(1) << 20)) fail("dataset '" + path + "' has a shape implausibly larger than the file");
+    readChunks(path, chunked, filters, out);
+  } else {
+    if (!filters.empty()) fail("dataset '" + path + "' has a filter pipeline but no chunked layout");
+    if (out.bytes.size() < n) fail("dataset '" + path + "' holds fewer bytes than its shape needs");
+  }
   out.bytes.resize(n);
   return out;
+}
+
+void File::walkChunkBtree(std::uint64_t node, std::size_t nDims, int depth,
+                          std::vector<std::pair<std::vector<std::uint64_t>, std::pair<std::uint64_t, std::pair<std::uint32_t, std::uint32_t>>>>& chunks) const {
+  if (depth > 16) fail("chunk B-tree is too deep");
+  if (node == kUndefined) return;                      // no chunk was ever written: the dataset reads as zeros
+  std::size_t p = (std::size_t)(base + node);
+  need(p, 8 + 2 * sizeOffsets, "a chunk B-tree node");
+  if (std::memcmp(&d[p], "TREE", 4) != 0) fail("bad chunk B-tree node signature");
+  if (d[p + 4] != 1) fail("expected a raw-data-chunk B-tree (node type 1), found type " + std::to_string(d[p + 4]));
+  const int level = d[p + 5];
+  const std::size_t used = u(p + 6, 2);
+  const std::size_t keySize = 8 + 8 * nDims;
+  std::size_t q = p + 8 + 2 * sizeOffsets;
+  for (std::size_t i = 0; i < used; ++i) {
+    need(q, keySize + sizeOffsets, "a chunk B-tree entry");
+    const std::uint32_t bytes = (std::uint32_t)u(q, 4), mask = (std::uint32_t)u(q + 4, 4);
+    std::vector<std::uint64_t> offset(nDims);
+    for (std::size_t k = 0; k < nDims; ++k) offset[k] = u(q + 8 + 8 * k, 8);
+    const std::uint64_t child = addr(q + keySize);
+    q += keySize + sizeOffsets;
+    if (level > 0) walkChunkBtree(child, nDims, depth + 1, chunks);
+    else chunks.push_back({std::move(offset), {child, {bytes, mask}}});
+    if (chunks.size() > (1u << 22)) fail("too many chunks");
+  }
+}
+
+void File::readChunks(const std::string& path, const ChunkedLayout& layout, const std::vector<Filter>& filters, Dataset& out) const {
+  const std::size_t rank = out.shape.size();
+  if (layout.dims.size() != rank + 1) fail("chunk rank of '" + path + "' does not match its dataspace");
+  const std::size_t es = layout.dims[rank];
+  if (es != out.elementSize) fail("chunk element size of '" + path + "' does not match its datatype");
+  std::size_t total = es, chunkBytes = es;
+  for (std::size_t k = 0; k < rank; ++k) {
+    if (layout.dims[k] == 0) fail("zero-sized chunk dimension in '" + path + "'");
+    total *= out.shape[k];
+    if (chunkBytes > (std::size_t(1) << 32) / layout.dims[k]) fail("implausible chunk size in '" + path + "'");
+    chunkBytes *= layout.dims[k];
+  }
+  if (chunkBytes > 64 * d.size() + (std::size_t(1) << 20)) fail("chunk shape of '" + path + "' is implausibly larger than the file");
+  out.bytes.assign(total, 0);                          // chunks never written read as the fill value (zero)
+  if (total == 0) return;
+  std::vector<std::pair<std::vector<std::uint64_t>, std::pair<std::uint64_t, std::pair<std::uint32_t, std::uint32_t>>>> chunks;
+  walkChunkBtree(layout.btree, rank + 1, 0, chunks);
+  std::vector<std::uint8_t> raw, tmp;
+  for (const auto& c : chunks) {
+    const auto& offset = c.first;
+    const std::uint64_t at = c.second.first;
+    const std::uint32_t stored = c.second.second.first, mask = c.second.second.second;
+    need((std::size_t)(base + at), stored, "a dataset chunk");
+    raw.assign(d.begin() + base + at, d.begin() + base + at + stored);
+    // undo the pipeline, last filter first (a set bit i of the chunk's mask: filter i was skipped for this chunk)
+    for (std::size_t fi = filters.size(); fi-- > 0;) {
+      if (mask & (1u << fi)) continue;
+      const Filter& f = filters[fi];
+      if (f.id == 3) {                                 // fletcher32: four checksum bytes behind the data
+        if (raw.size() < 4) fail("chunk of '" + path + "' is too short for its checksum");
+        raw.resize(raw.size() - 4);
+      } else if (f.id == 1) {                          // deflate
+        tmp.assign(chunkBytes, 0);
+        uLongf got = (uLongf)tmp.size();
+        const int rc = ::uncompress(tmp.data(), &got, raw.data(), (uLong)raw.size());
+        if (rc != Z_OK) fail("could not inflate a chunk of '" + path + "' (zlib error " + std::to_string(rc) + ")");
+        tmp.resize(got);
+        raw.swap(tmp);
+      } else if (f.id == 2) {                          // byte shuffle: [all byte 0s][all byte 1s]... -> elements
+        const std::size_t width = f.values.empty() ? es : f.values[0];
+        if (width > 1 && raw.size() >= width) {
+          const std::size_t count = raw.size() / width;
+          tmp.assign(raw.size(), 0);
+          for (std::size_t b = 0; b < width; ++b)
+            for (std::size_t e = 0; e < count; ++e) tmp[e * width + b] = raw[b * count + e];
+          std::copy(raw.begin() + count * width, raw.end(), tmp.begin() + count * width);
+          raw.swap(tmp);
+        }
+      }
+    }
+    if (raw.size() < chunkBytes) fail("a chunk of '" + path + "' holds fewer bytes than the chunk shape needs");
+    // copy the part of the chunk that lies inside the dataset, one innermost row at a time
+    for (std::size_t k = 0; k < rank; ++k)
+      if (offset[k] >= out.shape[k] || offset[k] % layout.dims[k]) fail("chunk offset outside the dataset '" + path + "'");
+    const std::size_t inner = rank ? std::min<std::size_t>(layout.dims[rank - 1], out.shape[rank - 1] - offset[rank - 1]) : 1;
+    std::vector<std::size_t> idx(rank, 0);             // position inside the chunk (all but the innermost dimension)
+    for (;;) {
+      std::size_t src = 0, dst = 0;
+      bool inside = true;
+      for (std::size_t k = 0; k + 1 < rank; ++k) {
+        src = src * layout.dims[k] + idx[k];
+        const std::size_t g = (std::size_t)offset[k] + idx[k];
+        if (g >= out.shape[k]) inside = false;
+        dst = dst * out.shape[k] + g;
+      }
+      if (inside) {
+        if (rank) { src = src * layout.dims[rank - 1]; dst = dst * out.shape[rank - 1] + (std::size_t)offset[rank - 1]; }
+        std::memcpy(&out.bytes[dst * es], &raw[src * es], inner * es);
+      }
+      std::size_t k = rank > 1 ? rank - 1 : 0;         // odometer over the outer dimensions
+      bool done = true;
+      while (k-- > 0) {
+        if (++idx[k] < layout.dims[k]) { done = false; break; }
+        idx[k] = 0;
+      }
+      if (done) break;
+    }
+  }
 }
 
 }  // namespace h5

@@ -4,9 +4,12 @@
 // Supported (HDF5 File Format Specification, version 0/1 superblock era -- what h5py's default libver produces):
 //   superblock v0/v1 (optionally behind a user block), version-1 object headers with continuation blocks,
 //   old-style groups (symbol-table message -> v1 B-tree -> SNOD nodes -> local heap), dataspace v1/v2,
-//   IEEE float datatypes, contiguous and compact data layouts (v1-v3), attributes v1-v3 holding fixed-length or
-//   variable-length (global heap) strings.
-// Anything else (chunked/compressed datasets, new-style groups, v2 object headers) raises std::runtime_error naming it.
+//   IEEE float datatypes, contiguous, compact and CHUNKED data layouts (v1-v3; chunks indexed by the version-1 chunk
+//   B-tree, edge chunks clipped, missing chunks read as zeros), the filters h5py applies for `compression="gzip"`,
+//   `shuffle=True` and `fletcher32=True` (deflate through zlib, byte shuffle, checksum stripped -- a per-chunk filter
+//   mask is honoured), attributes v1-v3 holding fixed-length or variable-length (global heap) strings.
+// Anything else (new-style groups, v2 object headers, version-4 layouts with their v2 B-tree / extensible-array chunk
+// indices, other filters) raises std::runtime_error naming exactly what was found -- e.g. "filter 32015 (zstd)".
 #pragma once
 #include <cstdint>
 #include <map>
@@ -48,6 +51,11 @@ private:
   std::uint64_t resolve(const std::string& path) const;
   std::map<std::string, Attribute> attributes(std::uint64_t headerAddress) const;
   std::string globalHeapObject(std::uint64_t collection, std::uint32_t index) const;
+  struct Filter { std::uint16_t id; std::vector<std::uint32_t> values; };
+  struct ChunkedLayout { std::uint64_t btree = 0; std::vector<std::size_t> dims; };   // dims: chunk shape, then the element size
+  void readChunks(const std::string& path, const ChunkedLayout& layout, const std::vector<Filter>& filters, Dataset& out) const;
+  void walkChunkBtree(std::uint64_t node, std::size_t nDims, int depth,
+                      std::vector<std::pair<std::vector<std::uint64_t>, std::pair<std::uint64_t, std::pair<std::uint32_t, std::uint32_t>>>>& chunks) const;
 
   std::vector<std::uint8_t> d;
   std::uint64_t base = 0;

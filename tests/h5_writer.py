@@ -1,5 +1,7 @@
 """Minimal HDF5 writer for test files (classic structures only: superblock v0, version-1 object headers, symbol-table
-groups with v1 B-tree / SNOD / local heap, contiguous datasets, fixed- and variable-length string attributes).
+groups with v1 B-tree / SNOD / local heap, contiguous or chunked datasets -- chunks indexed by a version-1 chunk B-tree
+of one or two levels, optionally through the gzip / shuffle / fletcher32 filters h5py offers -- fixed- and
+variable-length string attributes).
 
 Test infrastructure: it produces Keras-shaped `converted.hdf5` files for the dependency-free reader in
 ipu_path_trace_amd/host/Hdf5Reader.cpp (there is no h5py here).  The reader is additionally checked against a file
@@ -76,11 +78,78 @@ class H5Writer:
         return self._msg(0x000C, body), (len(struct.pack("<BBHHH", 1, 0, 0, 0, 0)) + len(_pad8(nm)) + len(_pad8(dt)) + len(_pad8(ds)) + 4 if vlen else None)
 
     # ---- objects
-    def dataset(self, array, attrs=None):
+    def dataset(self, array, attrs=None, chunks=None, compression=None, shuffle=False, fletcher32=False, filter_ids=None,
+                layout_version=3, leaf_fan=None, skip_chunks=()):
+        """chunks: chunk shape -> chunked layout (edge chunks stored full size, as libhdf5 does).  compression="gzip",
+        shuffle, fletcher32: the filter pipeline h5py writes for them, in h5py's order (shuffle, gzip, fletcher32).
+        filter_ids: extra filter ids appended to the pipeline message WITHOUT being applied (for rejection tests).
+        leaf_fan: entries per B-tree leaf (a second tree level appears when there are more chunks).  skip_chunks: chunk
+        indices left unwritten (they read back as zeros)."""
         a = np.ascontiguousarray(array)
-        raw = self._alloc(a.tobytes())
-        msgs = [self._msg(0x0001, self._dataspace(a.shape)), self._msg(0x0003, self._float_type(a.dtype.itemsize), flags=1),
-                self._msg(0x0008, struct.pack("<BBQQ", 3, 1, raw, a.nbytes))]
+        es = a.dtype.itemsize
+        msgs = [self._msg(0x0001, self._dataspace(a.shape)), self._msg(0x0003, self._float_type(es), flags=1)]
+        if chunks is None:
+            raw = self._alloc(a.tobytes())
+            msgs.append(self._msg(0x0008, struct.pack("<BBQQ", 3, 1, raw, a.nbytes)))
+            return self._finish_object(msgs, attrs)
+        import itertools
+        import zlib
+        filters = []                                  # (id, client values)
+        if shuffle:
+            filters.append((2, [es]))
+        if compression == "gzip":
+            filters.append((1, [4]))
+        if fletcher32:
+            filters.append((3, []))
+        entries = []                                  # (offset tuple, address, stored bytes)
+        grid = [range(0, s, c) for s, c in zip(a.shape, chunks)]
+        for ci, off in enumerate(itertools.product(*grid)):
+            if ci in skip_chunks:
+                continue
+            block = np.zeros(chunks, dtype=a.dtype)
+            sl = tuple(slice(o, min(o + c, s)) for o, c, s in zip(off, chunks, a.shape))
+            block[tuple(slice(0, x.stop - x.start) for x in sl)] = a[sl]
+            data = block.tobytes()
+            for fid, vals in filters:
+                if fid == 2:
+                    data = np.frombuffer(data, dtype=np.uint8).reshape(-1, es).T.tobytes()
+                elif fid == 1:
+                    data = zlib.compress(data, vals[0])
+                elif fid == 3:
+                    data = data + b"\0\0\0\0"
+            entries.append((off, self._alloc(data), len(data)))
+        nd = len(chunks) + 1
+
+        def key(off, nbytes):
+            return struct.pack("<II", nbytes, 0) + b"".join(struct.pack("<Q", o) for o in off) + struct.pack("<Q", 0)
+
+        def node(level, items):                        # items: (first offset, child address, stored bytes)
+            body = b"TREE" + struct.pack("<BBHQQ", 1, level, len(items), UNDEF, UNDEF)
+            for off, child, nbytes in items:
+                body += key(off, nbytes) + struct.pack("<Q", child)
+            body += key(tuple(a.shape), 0)             # the final key
+            return self._alloc(body)
+
+        if not entries:
+            tree = UNDEF
+        elif leaf_fan and len(entries) > leaf_fan:
+            leaves = [entries[i:i + leaf_fan] for i in range(0, len(entries), leaf_fan)]
+            tree = node(1, [(part[0][0], node(0, part), 0) for part in leaves])
+        else:
+            tree = node(0, entries)
+        dims = b"".join(struct.pack("<I", c) for c in chunks) + struct.pack("<I", es)
+        if layout_version == 3:
+            msgs.append(self._msg(0x0008, struct.pack("<BBB", 3, 2, nd) + struct.pack("<Q", tree) + dims))
+        else:
+            msgs.append(self._msg(0x0008, struct.pack("<BBB5x", layout_version, nd, 2) + struct.pack("<Q", tree) + dims))
+        ids = filters + [(i, []) for i in (filter_ids or [])]
+        if ids:
+            body = struct.pack("<BB6x", 1, len(ids))
+            for fid, vals in ids:
+                name = b"" if fid < 256 else b"thirdparty\0"
+                body += struct.pack("<HHHH", fid, len(_pad8(name)), 1, len(vals)) + _pad8(name)
+                body += b"".join(struct.pack("<I", v) for v in vals) + (b"\0\0\0\0" if len(vals) & 1 else b"")
+            msgs.append(self._msg(0x000B, body))
         return self._finish_object(msgs, attrs)
 
     def _finish_object(self, msgs, attrs):
@@ -144,7 +213,7 @@ class H5Writer:
         return bytes(self.buf)
 
 
-def write_keras_h5(path, layers, vlen_config=False, user_block=0, snod_capacity=8, with_concat=True):
+def write_keras_h5(path, layers, vlen_config=False, user_block=0, snod_capacity=8, with_concat=True, **dataset_options):
     """Keras "Functional" H5 of a NIF: layers = [(kernel [in,out], bias | None, relu)], dataset paths
     /model_weights/<name>/<name>/{kernel:0,bias:0} (reference src/keras/Hdf5Model.cpp:71-82)."""
     import json
@@ -159,9 +228,14 @@ def write_keras_h5(path, layers, vlen_config=False, user_block=0, snod_capacity=
         cfg_layers.append({"class_name": "Dense", "config": {"name": name, "dtype": dt, "units": int(k.shape[1]),
                                                               "activation": "relu" if relu else "linear",
                                                               "use_bias": b is not None}})
-        inner = {"kernel:0": w.dataset(k)}
+        opts = dict(dataset_options)
+        if "chunks" in opts:                           # (rows, cols) for the kernels; the biases take the column count
+            opts["chunks"] = tuple(min(c, s) for c, s in zip(opts["chunks"], k.shape))
+        inner = {"kernel:0": w.dataset(k, **opts)}
         if b is not None:
-            inner["bias:0"] = w.dataset(b)
+            if "chunks" in opts:
+                opts["chunks"] = (min(dataset_options["chunks"][1], b.shape[0]),)
+            inner["bias:0"] = w.dataset(b, **opts)
         layer_groups[name] = w.group({name: w.group(inner)}, attrs={"weight_names": name})
     config = json.dumps({"class_name": "Functional", "config": {"name": "model", "layers": cfg_layers}})
     weights = w.group(layer_groups, attrs={"backend": "tensorflow", "keras_version": "2.8.0"})

@@ -74,6 +74,59 @@ def test_keras_h5_roundtrip(host, tmp_path, vlen, user_block, cap):
         assert ksum == int(k.view(np.uint16).astype(np.uint64).sum())
 
 
+@pytest.mark.parametrize("opts", [
+    dict(chunks=(16, 24)),                                                    # chunked, no filter (edge chunks on both axes)
+    dict(chunks=(16, 24), layout_version=1),                                  # the version-1 layout message
+    dict(chunks=(8, 8), leaf_fan=5),                                          # two-level chunk B-tree
+    dict(chunks=(32, 32), compression="gzip"),                                # h5py compression="gzip"
+    dict(chunks=(32, 32), compression="gzip", shuffle=True),                  # ... with shuffle=True
+    dict(chunks=(16, 64), compression="gzip", shuffle=True, fletcher32=True),
+    dict(chunks=(64, 64), shuffle=True),
+])
+def test_chunked_and_filtered_datasets(host, tmp_path, opts):
+    """Hdf5Model.cpp:96-133 reads the variables through libhdf5, which takes any layout; a Keras file whose weights were
+    written chunked (h5py does that for any compression / shuffle / resizable dataset) must load into the same layers."""
+    layers = nif_assets.synthetic_nif(hidden=80, layer_count=3, seed=5)        # 48x80, 80x80 (+48 concat), 80x3: ragged chunk edges
+    p = str(tmp_path / "chunked.hdf5")
+    write_keras_h5(p, layers, **opts)
+    for i, (k, b, _) in enumerate(layers):
+        name = "dense" if i == 0 else "dense_%d" % i
+        shape, el, raw = _dataset(host, p, "/model_weights/%s/%s/kernel:0" % (name, name))
+        assert shape == k.shape and el == 2 and raw.tobytes() == k.tobytes(), (name, opts)
+        shape, el, raw = _dataset(host, p, "/model_weights/%s/%s/bias:0" % (name, name))
+        assert shape == b.shape and raw.tobytes() == b.tobytes()
+    out, err = np.zeros(64, np.uint64), C.create_string_buffer(512)
+    assert host.pth_h5_model(p.encode(), out.ctypes.data, out.size, err, 512) == len(layers), err.value
+    for i, (k, b, relu) in enumerate(layers):
+        assert int(out[6 * i + 5]) == int(k.view(np.uint16).astype(np.uint64).sum())
+
+
+def test_missing_chunks_read_as_zeros_and_unknown_filters_are_named(host, tmp_path):
+    from tests.h5_writer import H5Writer
+    a = np.arange(40 * 30, dtype=np.float32).reshape(40, 30)
+    w = H5Writer()
+    root = w.group({"sparse": w.dataset(a, chunks=(16, 16), skip_chunks=(1, 4)),
+                    "float32_gzip": w.dataset(a, chunks=(16, 16), compression="gzip", shuffle=True),
+                    "zstd": w.dataset(a, chunks=(16, 16), filter_ids=[32015]),
+                    "szip": w.dataset(a, chunks=(16, 16), compression="gzip", filter_ids=[4]),
+                    "never_written": w.dataset(a, chunks=(16, 16), skip_chunks=tuple(range(6)))})
+    p = str(tmp_path / "f.h5")
+    open(p, "wb").write(w.finish(root))
+    exp = a.copy()
+    exp[0:16, 16:30] = 0                                                      # chunk 1 = rows 0-15, columns 16-29
+    exp[32:40, 0:16] = 0                                                      # chunk 4 = rows 32-39, columns 0-15
+    shape, el, raw = _dataset(host, p, "/sparse")
+    assert shape == (40, 30) and el == 4 and np.array_equal(raw.view(np.float32).reshape(40, 30), exp)
+    shape, el, raw = _dataset(host, p, "/float32_gzip")
+    assert np.array_equal(raw.view(np.float32).reshape(40, 30), a)
+    shape, el, raw = _dataset(host, p, "/never_written")
+    assert not raw.any()
+    with pytest.raises(RuntimeError, match=r"filter 32015 \(zstd\)"):
+        _dataset(host, p, "/zstd")
+    with pytest.raises(RuntimeError, match=r"filter 4 \(szip\)"):
+        _dataset(host, p, "/szip")
+
+
 def test_unsupported_content_is_reported(host, tmp_path):
     p = tmp_path / "not_hdf5.h5"
     p.write_bytes(b"this is not an HDF5 file" * 10)
@@ -124,17 +177,19 @@ def test_truncated_and_corrupted_files_fail_cleanly(tmp_path):
     srcs = [os.path.join(HOST, f) for f in ("Hdf5Reader.cpp", "Hdf5Model.cpp", "NifModel.cpp")]
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
                            "-I" + HOST, "-I" + os.path.join(ROOT, "include"), "-o", exe,
-                           os.path.join(ROOT, "tests", "h5fuzz_main.cpp")] + srcs + ["-Wl,--unresolved-symbols=ignore-all"])
+                           os.path.join(ROOT, "tests", "h5fuzz_main.cpp")] + srcs + ["-lz", "-Wl,--unresolved-symbols=ignore-all"])
     layers = nif_assets.synthetic_nif(hidden=32, layer_count=2, embedding_dim=4)
     meta = tmp_path / "nif_metadata.txt"
     nif_assets.write_metadata(str(meta), dict(nif_assets.URBAN_ALLEY_META, embedding_dimension=4, hidden_size=32, layer_count=2))
     good = tmp_path / "good.hdf5"
     write_keras_h5(str(good), layers, vlen_config=True)
+    chunked = tmp_path / "chunked.hdf5"                                  # chunk B-tree, inflate and un-shuffle under the fuzzer too
+    write_keras_h5(str(chunked), layers, chunks=(8, 16), compression="gzip", shuffle=True, fletcher32=True, leaf_fan=3)
     ptn = tmp_path / "good.ptnif"
     nif_assets.write_ptnif(str(ptn), layers, 4)
     rng = np.random.default_rng(0)
-    files = [str(good), str(ptn)]
-    for src, ext in ((good, ".hdf5"), (ptn, ".ptnif")):
+    files = [str(good), str(chunked), str(ptn)]
+    for src, ext in ((good, ".hdf5"), (chunked, ".c.hdf5"), (ptn, ".ptnif")):
         raw = np.fromfile(str(src), dtype=np.uint8)
         cuts = sorted(set(list(range(0, min(raw.size, 700), 7)) + list(rng.integers(0, raw.size, 60))))
         for k, n in enumerate(cuts):                                   # truncations
@@ -152,4 +207,4 @@ def test_truncated_and_corrupted_files_fail_cleanly(tmp_path):
                        env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0:allocator_may_return_null=1"))
     assert r.returncode == 0, r.stderr[-3000:]
     loaded, rejected = [int(x) for x in r.stdout.strip().splitlines()[-1].split()[1::2]]
-    assert loaded >= 2 and rejected > 100 and loaded + rejected == len(files)
+    assert loaded >= 3 and rejected > 150 and loaded + rejected == len(files)
