@@ -38,8 +38,11 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
                                               uint32_t k1, uint32_t out[4]) {
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
-    uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-    uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    // one 32 x 32 -> 64 multiply per product (v_mad_u64_u32) instead of a v_mul_hi_u32 / v_mul_lo_u32 pair: the integer
+    // multiplies run at quarter rate, and there are forty of them per block in the paired form
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+    const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
     uint32_t n0 = hi1 ^ c1 ^ k0;
     uint32_t n2 = hi0 ^ c3 ^ k1;
     c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
@@ -94,12 +97,15 @@ __device__ __forceinline__ void dm_sincos2pi(float u, float& s_out, float& c_out
   c_out = (q == 1 || q == 2) ? -c : c;
 }
 
+// (Written with selects instead of branches: on a 64-lane wave both sides of a data-dependent branch run one after the
+// other whenever the lanes disagree -- for atan2 that was two divisions and two polynomials per call.  Every lane still
+// evaluates exactly the expressions of the branchy form the oracle has: the value a lane does not take is computed and
+// dropped, so the results are bit-identical.)
 __device__ __forceinline__ float dm_atan01(float t) {
-  float base = 0.0f;
-  if (t > 0.414213567972183227539062f) {
-    t = (t - 1.0f) / (t + 1.0f);
-    base = 0.785398185253143310546875f;
-  }
+  const bool big = t > 0.414213567972183227539062f;
+  const float reduced = (t - 1.0f) / (t + 1.0f);
+  t = big ? reduced : t;
+  const float base = big ? 0.785398185253143310546875f : 0.0f;
   float z = t * t;
   float p = 0x1.9e0c4cp-5f;
   p = p * z - 0x1.61601ep-4f;
@@ -114,19 +120,19 @@ __device__ __forceinline__ float dm_atan2(float y, float x) {
   const float pi = 3.1415927410125732421875f;
   const float pio2 = 1.57079637050628662109375f;
   float ax = fabsf(x), ay = fabsf(y);
-  if (ax == 0.0f && ay == 0.0f) return 0.0f;
-  float r;
-  if (ay <= ax) r = dm_atan01(ay / ax);
-  else r = pio2 - dm_atan01(ax / ay);
+  const bool zero = (ax == 0.0f && ay == 0.0f);
+  const bool steep = !(ay <= ax);
+  const float a = dm_atan01((steep ? ax : ay) / (steep ? ay : ax));   // ay / ax, or ax / ay for the steep half
+  float r = steep ? pio2 - a : a;
   if (x < 0.0f) r = pi - r;
-  return (y < 0.0f) ? -r : r;
+  r = (y < 0.0f) ? -r : r;
+  return zero ? 0.0f : r;
 }
 
 __device__ __forceinline__ float dm_acos(float x) {
-  if (x >= 1.0f) return 0.0f;
-  if (x <= -1.0f) return 3.1415927410125732421875f;
   float s = sqrtf((1.0f - x) * (1.0f + x));
-  return dm_atan2(s, x);
+  const float r = dm_atan2(s, x);
+  return (x >= 1.0f) ? 0.0f : ((x <= -1.0f) ? 3.1415927410125732421875f : r);
 }
 
 }  // namespace ptd

@@ -2,10 +2,21 @@
 //
 // Replaces the reference's GenerateCameraRays / RayTraceKernel / PreProcessEscapedRays codelets
 // (src/codelets/codelets.cpp:36-80, :93-227, :312-358) and the poprand noise tensors
-// (src/PathTracerApp.cpp:266-299).  One lane carries one path in registers; a lane whose path
-// ends is refilled from the wave's share of the batch (wave ballot + mbcnt prefix), and escaped
-// paths are appended to the workgroup's region of the NIF queue (ballot + one LDS atomic per
-// wave), so the queue the MFMA kernel reads is dense and no ray state ever goes to HBM.
+// (src/PathTracerApp.cpp:266-299).  One lane carries one path in registers and escaped paths are
+// appended to the workgroup's region of the NIF queue (ballot + one LDS atomic per wave), so the
+// queue the MFMA kernel reads is dense and no ray state ever goes to HBM.
+//
+// Round 3: two phases per workgroup.  60 % of the camera rays hit nothing and end after ONE
+// intersection test; in the round-2 kernel every loop trip therefore re-generated more than half
+// of the wave's lanes -- noise, camera ray, normalisation: the costliest stretch of the kernel --
+// with only those lanes active, and bounced the rest beside them (55 % lane utilisation).  Now a
+// workgroup first runs ALL its camera rays, 64 new paths per wave and trip, every lane active
+// (primary phase: ray generation + first intersection; a miss is final and goes to the queue, a
+// hit leaves an 8-byte note -- path index and the half-rounded camera ray -- in the workgroup's
+// survivor list, which stays in L2), and then bounces the survivors in the persistent loop
+// (secondary phase), where a lane whose path ends is refilled from the list for the price of one
+// load and a normalisation, so the wave stays full.  Same device functions in the same order on
+// the same values: bit-identical paths (tests/test_gpu_parity.py).
 #pragma once
 #include "pt_device_math.h"
 
@@ -50,6 +61,7 @@ struct TraceParams {
   uint32_t* region_count;    // [gridDim.x]
   uint8_t* plen;             // [total_paths] length | escaped<<7
   float* rad_r; float* rad_g; float* rad_b;  // [total_paths] (constant-env mode writes here)
+  uint2* survivors;          // [gridDim.x][region_cap] primary-phase notes: path index, camera ray (two halves)
 };
 
 struct PathState {
@@ -119,7 +131,7 @@ __device__ __forceinline__ float sphere_intersect(Vec3 o, Vec3 d, const SceneObj
   float b = 2.0f * dot(oc, d);
   float c_ = dot(oc, oc) - ob.r2;
   float disc = b * b - 4.0f * c_;
-  if (disc < 0.0f) return 0.0f;
+  if (disc < 0.0f) return 0.0f;   // (a real branch on purpose: a wave none of whose rays comes near the sphere skips the rest)
   disc = sqrtf(disc);
   float sol1 = -b + disc;
   float sol2 = -b - disc;
@@ -131,11 +143,26 @@ __device__ __forceinline__ float disc_intersect(Vec3 o, Vec3 d, const SceneObjec
   float denom = dot(n, d);
   if (denom == 0.0f) return 0.0f;
   float t = dot(sub(c, o), n) / denom;
-  if (!(t > kEps)) return 0.0f;
+  if (!(t > kEps)) return 0.0f;   // (real branches on purpose, as in sphere_intersect)
   Vec3 p = add(o, scale(d, t));
   Vec3 pc = sub(p, c);
   if (dot(pc, pc) > ob.r2) return 0.0f;
   return t;
+}
+
+// Scene::intersect (codelets.cpp:183): nearest hit in declaration order, -1 for none.
+// The loop stays rolled: one object's constants at a time are fetched from the kernel-argument segment (scalar
+// loads, wave-uniform), instead of all of them living in SGPRs.
+__device__ __forceinline__ int nearest_hit(const TraceParams& P, Vec3 o, Vec3 d, float& tbest) {
+  int best = -1;
+  tbest = kInf;
+#pragma unroll 1
+  for (int i = 0; i < kNumObjects; ++i) {
+    const SceneObject ob = P.obj[i];
+    float t = ob.is_disc ? disc_intersect(o, d, ob) : sphere_intersect(o, d, ob);
+    if (t > kEps && t < tbest) { tbest = t; best = i; }
+  }
+  return best;
 }
 
 enum StepResult { STEP_CONTINUE = 0, STEP_ESCAPED = 1, STEP_DEAD = 2 };
@@ -175,17 +202,8 @@ __device__ __forceinline__ int bounce(const TraceParams& P, const HitRow* tab, P
     }
     rr = P.rr_factor;
   }
-  // Scene::intersect (:183): nearest hit in declaration order.
-  // The loop stays rolled: one object's constants at a time are fetched from the kernel-argument segment (scalar
-  // loads, wave-uniform), instead of all of them living in SGPRs.
-  int best = -1;
-  float tbest = kInf;
-#pragma unroll 1
-  for (int i = 0; i < kNumObjects; ++i) {
-    const SceneObject ob = P.obj[i];
-    float t = ob.is_disc ? disc_intersect(s.o, s.d, ob) : sphere_intersect(s.o, s.d, ob);
-    if (t > kEps && t < tbest) { tbest = t; best = i; }
-  }
+  float tbest;
+  const int best = nearest_hit(P, s.o, s.d, tbest);           // Scene::intersect (:183)
   if (best < 0) {                                             // :184-190 ESCAPED
     s.T = scale(s.T, rr);
     length = s.depth + 1u;
@@ -203,12 +221,12 @@ __device__ __forceinline__ int bounce(const TraceParams& P, const HitRow* tab, P
     float u1 = uniform01(w[1], P.samples_half);
     float u2 = uniform01(w[2], P.samples_half);
     Vec3 rx, ry;
-    if (fabsf(n.x) > fabsf(n.y)) {
-      float inv = 1.0f / sqrtf(n.x * n.x + n.z * n.z);
-      rx = mk(-n.z * inv, 0.0f, n.x * inv);
-    } else {
-      float inv = 1.0f / sqrtf(n.y * n.y + n.z * n.z);
-      rx = mk(0.0f, n.z * inv, -n.y * inv);
+    {   // the branch of light::diffuse's basis as selects: one square root and one division per lane, not two of each per wave
+      const bool xmajor = fabsf(n.x) > fabsf(n.y);
+      const float m = xmajor ? n.x : n.y;
+      const float inv = 1.0f / sqrtf(m * m + n.z * n.z);
+      const float a = n.z * inv, b = m * inv;
+      rx = xmajor ? mk(-a, 0.0f, b) : mk(0.0f, a, -b);
     }
     ry = cross(n, rx);
     float r = sqrtf(1.0f - u1 * u1);
@@ -235,8 +253,11 @@ __device__ __forceinline__ int bounce(const TraceParams& P, const HitRow* tab, P
     float m2 = m * m;
     float rprob = r0 + (1.0f - r0) * (m2 * m2 * m);
     bool refracted = (cost2 > 0.0f && u > rprob);
-    if (refracted) s.d = normalise(add(scale(s.d, nn), scale(n, nn * cost1 - sqrtf(cost2))));
-    else s.d = normalise(add(s.d, scale(n, cost1 * 2.0f)));
+    {   // one normalisation per lane: the vector is chosen first (sqrtf of a negative cost2 only feeds the side not taken)
+      const Vec3 bent = add(scale(s.d, nn), scale(n, nn * cost1 - sqrtf(cost2)));
+      const Vec3 mirrored = add(s.d, scale(n, cost1 * 2.0f));
+      s.d = normalise(refracted ? bent : mirrored);
+    }
     Vec3 tint = refracted ? mk(cr, cg, cb) : mk(1.f, 1.f, 1.f);
     s.T = scale(cwise(s.T, tint), 1.15f * rr);
   }
@@ -262,45 +283,121 @@ __device__ __forceinline__ void dir_to_uv(Vec3 d, float azimuth, float& u, float
 }
 
 constexpr int kTraceBlock = 256;
-constexpr uint32_t kRefillThreshold = 20;  // refill once this many lanes are idle (or none is active)
+constexpr uint32_t kRefillThreshold = 16;  // secondary phase: refill once this many lanes are idle (or none is active); 1..24 measured within 1 %
 
-__global__ __launch_bounds__(kTraceBlock) void trace_kernel(const TraceParams P) {
-  __shared__ uint32_t wg_count;
+// An escaped path: constant environment -> radiance straight into the per-path result; NIF -> one entry in the
+// workgroup's region of the queue (wave ballot + prefix count, ONE LDS atomic per wave, uv of PreProcessEscapedRays).
+__device__ __forceinline__ void emit_escaped(const TraceParams& P, bool escaped, const PathState& st, uint32_t idx, uint32_t lane,
+                                             uint32_t region_base, uint32_t* wg_count) {
+  if (P.env_const) {
+    if (escaped) {  // constant environment: total = env (.) T, no NIF
+      P.rad_r[idx] = P.env_r * st.T.x;
+      P.rad_g[idx] = P.env_g * st.T.y;
+      P.rad_b[idx] = P.env_b * st.T.z;
+    }
+    return;
+  }
+  const uint64_t esc_mask = __ballot(escaped);
+  if (!esc_mask) return;
+  uint32_t base = 0;
+  if (lane == (uint32_t)__ffsll((long long)esc_mask) - 1u) base = atomicAdd(wg_count, (uint32_t)__popcll(esc_mask));
+  base = __shfl(base, __ffsll((long long)esc_mask) - 1, 64);
+  if (escaped) {
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(esc_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)esc_mask, 0u));
+    const uint32_t q = region_base + base + rank;
+    float u, v;
+    dir_to_uv(st.d, P.azimuth, u, v);
+    P.q_u[q] = u; P.q_v[q] = v;
+    P.q_tr[q] = st.T.x; P.q_tg[q] = st.T.y; P.q_tb[q] = st.T.z;
+    P.q_path[q] = idx;
+  }
+}
+
+__device__ __forceinline__ uint32_t pack_half2(float a, float b) {   // both are exact halves (hround): lossless
+  union { _Float16 h[2]; uint32_t u; } c;
+  c.h[0] = (_Float16)a; c.h[1] = (_Float16)b;
+  return c.u;
+}
+
+template <uint32_t REFILL>
+__device__ __forceinline__ void trace_body(const TraceParams& P) {
+  __shared__ uint32_t wg_count;   // escaped paths queued by this workgroup
+  __shared__ uint32_t wg_surv;    // camera rays of this workgroup that hit something
   __shared__ HitRow hit_table[kNumObjects];
-  if (threadIdx.x == 0) { wg_count = 0; fill_hit_table(P, hit_table); }
+  if (threadIdx.x == 0) { wg_count = 0; wg_surv = 0; fill_hit_table(P, hit_table); }
   __syncthreads();
 
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t gw = blockIdx.x * (kTraceBlock / 64) + (threadIdx.x >> 6);
+  const uint32_t wib = threadIdx.x >> 6;                              // wave in the workgroup
+  const uint32_t gw = blockIdx.x * (kTraceBlock / 64) + wib;
   const uint32_t region_base = blockIdx.x * P.region_cap;
-  uint32_t cursor = 0;  // next unassigned j of this wave's strided path sequence
-  // paths this wave owns: j -> idx = ((j / 64) * n_waves + gw) * 64 + (j % 64)
+  uint2* const surv = P.survivors + (size_t)region_base;
+  // paths this wave owns: chunk j -> idx = (j * n_waves + gw) * 64 + lane
   const uint32_t n_chunks = (P.total_paths + 63u) / 64u;
   const uint32_t my_chunks = (n_chunks > gw) ? (n_chunks - gw + P.n_waves - 1u) / P.n_waves : 0u;
-  const uint32_t my_paths = my_chunks * 64u;
 
+  // ---- primary phase: every lane starts a new path each trip (GenerateCameraRays + the first Scene::intersect)
+  for (uint32_t j = 0; j < my_chunks; ++j) {
+    const uint32_t idx = (j * P.n_waves + gw) * 64u + lane;
+    const bool valid = idx < P.total_paths;
+    PathState st;
+    float camx = 0.f, camy = 0.f;
+    bool hit = false;
+    if (valid) {
+      start_path(P, P.pix[idx % P.n_items], P.sample_base + idx / P.n_items, st, camx, camy);
+      float t;
+      hit = nearest_hit(P, st.o, st.d, t) >= 0;
+    }
+    // a miss at depth 0 is final (codelets.cpp:184-190): one record, no roulette below roulette_depth >= 1, so the
+    // throughput is (1, 1, 1) x 1 exactly as bounce() would leave it
+    const bool escaped = valid && !hit;
+    if (escaped) P.plen[idx] = (uint8_t)(1u | 0x80u);
+    emit_escaped(P, escaped, st, idx, lane, region_base, &wg_count);
+    const uint64_t hit_mask = __ballot(hit);
+    if (hit_mask) {
+      uint32_t base = 0;
+      if (lane == (uint32_t)__ffsll((long long)hit_mask) - 1u) base = atomicAdd(&wg_surv, (uint32_t)__popcll(hit_mask));
+      base = __shfl(base, __ffsll((long long)hit_mask) - 1, 64);
+      if (hit) {
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(hit_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hit_mask, 0u));
+        surv[base + rank] = make_uint2(idx, pack_half2(camx, camy));
+      }
+    }
+  }
+  __syncthreads();   // the workgroup's survivor list is complete (and visible: the workgroup's own global stores, first read now)
+  const uint32_t n_surv = wg_surv;
+
+  // ---- secondary phase: the path loop over the survivors, persistent lanes.  Wave w owns entries
+  // e(j) = ((j / 64) * 4 + w) * 64 + j % 64 of the list; an idle lane takes the next one: camera ray from its two halves,
+  // then bounce() from depth 0 (the first intersection is recomputed: cheaper than carrying its result through memory)
+  uint32_t cursor = 0;
+  const uint32_t s_chunks = (n_surv + 63u) / 64u;
+  const uint32_t mine = (s_chunks > wib) ? (s_chunks - wib + 3u) / 4u * 64u : 0u;
   PathState st;
   uint32_t idx = 0;
   bool active = false;
-
   while (true) {
     const uint64_t act_mask = __ballot(active);
     const uint32_t n_active = (uint32_t)__popcll(act_mask);
-    const bool more = cursor < my_paths;
+    const bool more = cursor < mine;
     if (!more && n_active == 0) break;
-    if (more && (n_active == 0 || 64u - n_active >= kRefillThreshold)) {
-      // hand the next paths of the wave's sequence to the idle lanes (ballot + prefix count)
+    if (more && (n_active == 0 || 64u - n_active >= REFILL)) {
       const uint64_t idle = ~act_mask;
       const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
       if (!active) {
         const uint32_t j = cursor + rank;
-        const uint32_t cand = ((j >> 6) * P.n_waves + gw) * 64u + (j & 63u);
-        if (j < my_paths && cand < P.total_paths) {
-          idx = cand;
-          const uint32_t item = cand % P.n_items;
-          const uint32_t iter = cand / P.n_items;
-          float camx, camy;
-          start_path(P, P.pix[item], P.sample_base + iter, st, camx, camy);
+        const uint32_t e = ((j >> 6) * 4u + wib) * 64u + (j & 63u);
+        if (j < mine && e < n_surv) {
+          const uint2 note = surv[e];
+          idx = note.x;
+          union { uint32_t u; _Float16 h[2]; } c;
+          c.u = note.y;
+          st.o = mk(0.f, 0.f, 0.f);
+          st.d = normalise(mk((float)c.h[0], (float)c.h[1], -1.f));     // as start_path (codelets.cpp:162-163)
+          st.T = mk(1.f, 1.f, 1.f);
+          st.pixel = P.pix[idx % P.n_items];
+          st.sample = P.sample_base + idx / P.n_items;
+          st.depth = 0;
           active = true;
         }
       }
@@ -315,33 +412,17 @@ __global__ __launch_bounds__(kTraceBlock) void trace_kernel(const TraceParams P)
       P.plen[idx] = (uint8_t)(length | (escaped ? 0x80u : 0u));
       active = false;
     }
-    if (P.env_const) {
-      if (escaped) {  // constant environment: total = env (.) T, no NIF
-        P.rad_r[idx] = P.env_r * st.T.x;
-        P.rad_g[idx] = P.env_g * st.T.y;
-        P.rad_b[idx] = P.env_b * st.T.z;
-      }
-    } else {
-      const uint64_t esc_mask = __ballot(escaped);
-      if (esc_mask) {
-        uint32_t base = 0;
-        if (lane == (uint32_t)__ffsll((long long)esc_mask) - 1u) base = atomicAdd(&wg_count, (uint32_t)__popcll(esc_mask));
-        base = __shfl(base, __ffsll((long long)esc_mask) - 1, 64);
-        if (escaped) {
-          const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(esc_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)esc_mask, 0u));
-          const uint32_t q = region_base + base + rank;
-          float u, v;
-          dir_to_uv(st.d, P.azimuth, u, v);
-          P.q_u[q] = u; P.q_v[q] = v;
-          P.q_tr[q] = st.T.x; P.q_tg[q] = st.T.y; P.q_tb[q] = st.T.z;
-          P.q_path[q] = idx;
-        }
-      }
-    }
+    emit_escaped(P, escaped, st, idx, lane, region_base, &wg_count);
   }
   __syncthreads();
   if (threadIdx.x == 0) P.region_count[blockIdx.x] = wg_count;
 }
+
+__global__ __launch_bounds__(kTraceBlock) void trace_kernel(const TraceParams P) { trace_body<kRefillThreshold>(P); }
+#ifdef PTMI_DIAG_BUILD
+template <uint32_t REFILL>
+__global__ __launch_bounds__(kTraceBlock) void trace_kernel_refill(const TraceParams P) { trace_body<REFILL>(P); }   // threshold sweep
+#endif
 
 struct PathRecordOut {  // layout of pt_path_record (include/ptmi.h)
   uint32_t length, escaped;

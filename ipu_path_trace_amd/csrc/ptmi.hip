@@ -25,6 +25,9 @@
 #include "diag/pt_nif_variants.h"
 #endif
 #include "pt_trace.h"
+#ifdef PTMI_DIAG_BUILD
+#include "diag/pt_trace_v1.h"
+#endif
 
 namespace {
 
@@ -93,6 +96,7 @@ struct pt_context {
   struct BatchBuffers {
     float *q_u = nullptr, *q_v = nullptr, *q_tr = nullptr, *q_tg = nullptr, *q_tb = nullptr;
     uint32_t* q_path = nullptr;
+    uint2* survivors = nullptr;        // primary-phase notes of the trace kernel, one region per trace workgroup
     uint32_t* region_count = nullptr;
     uint8_t* plen = nullptr;
     float *rad_r = nullptr, *rad_g = nullptr, *rad_b = nullptr;
@@ -244,6 +248,7 @@ void fill_trace_params(pt_handle h, ptd::TraceParams& P) {
 void bind_batch(ptd::TraceParams& P, const pt_context::BatchBuffers& B) {
   P.q_u = B.q_u; P.q_v = B.q_v; P.q_tr = B.q_tr; P.q_tg = B.q_tg; P.q_tb = B.q_tb; P.q_path = B.q_path;
   P.region_count = B.region_count;
+  P.survivors = B.survivors;
   P.plen = B.plen;
   P.rad_r = B.rad_r; P.rad_g = B.rad_g; P.rad_b = B.rad_b;
 }
@@ -945,7 +950,7 @@ int launch_nif(pt_handle h, const ptd::NifParams& N, int blocks) {
 void free_batch_buffers(pt_handle h) {
   for (auto& B : h->bb) {
     (void)hipFree(B.q_u); (void)hipFree(B.q_v); (void)hipFree(B.q_tr); (void)hipFree(B.q_tg); (void)hipFree(B.q_tb);
-    (void)hipFree(B.q_path); (void)hipFree(B.region_count); (void)hipFree(B.plen);
+    (void)hipFree(B.q_path); (void)hipFree(B.survivors); (void)hipFree(B.region_count); (void)hipFree(B.plen);
     (void)hipFree(B.rad_r); (void)hipFree(B.rad_g); (void)hipFree(B.rad_b);
     if (B.traced) (void)hipEventDestroy(B.traced);
     if (B.accumulated) (void)hipEventDestroy(B.accumulated);
@@ -1037,6 +1042,7 @@ int pt_create(const pt_config* cfg, pt_handle* out) {
     PT_HIPC(dev_alloc(&B.q_tg, h->queue_cap));
     PT_HIPC(dev_alloc(&B.q_tb, h->queue_cap));
     PT_HIPC(dev_alloc(&B.q_path, h->queue_cap));
+    PT_HIPC(dev_alloc(&B.survivors, h->queue_cap));
     PT_HIPC(dev_alloc(&B.region_count, (size_t)ptd::kMaxRegions));
     PT_HIPC(dev_alloc(&B.plen, h->batch_paths_cap));
     PT_HIPC(dev_alloc(&B.rad_r, h->batch_paths_cap));
@@ -1286,6 +1292,21 @@ static int enqueue_path_trace(pt_handle h, std::vector<StageSpan>& spans, size_t
     if (!t0 || !t1 || !n0 || !n1 || !a1 || !a0) return fail(h, PT_ERR_HIP, "hipEventCreate failed");
     if (batch >= 2) PT_HIP(hipStreamWaitEvent(h->trace_stream, B.accumulated, 0));
     PT_HIP(hipEventRecord(t0, h->trace_stream));
+#ifdef PTMI_DIAG_BUILD
+    // A/B switch of the profiling build, read per launch: the round-2 one-phase kernel
+    const char* tk = getenv("PTMI_TRACE_KERNEL");
+    if (tk && !strcmp(tk, "v1"))
+      hipLaunchKernelGGL(ptd::trace_kernel_v1, dim3(g.blocks), dim3(ptd::kTraceBlock), 0, h->trace_stream, P);
+    else if (tk && !strcmp(tk, "r1"))
+      hipLaunchKernelGGL(ptd::trace_kernel_refill<1>, dim3(g.blocks), dim3(ptd::kTraceBlock), 0, h->trace_stream, P);
+    else if (tk && !strcmp(tk, "r4"))
+      hipLaunchKernelGGL(ptd::trace_kernel_refill<4>, dim3(g.blocks), dim3(ptd::kTraceBlock), 0, h->trace_stream, P);
+    else if (tk && !strcmp(tk, "r16"))
+      hipLaunchKernelGGL(ptd::trace_kernel_refill<16>, dim3(g.blocks), dim3(ptd::kTraceBlock), 0, h->trace_stream, P);
+    else if (tk && !strcmp(tk, "r24"))
+      hipLaunchKernelGGL(ptd::trace_kernel_refill<24>, dim3(g.blocks), dim3(ptd::kTraceBlock), 0, h->trace_stream, P);
+    else
+#endif
     hipLaunchKernelGGL(ptd::trace_kernel, dim3(g.blocks), dim3(ptd::kTraceBlock), 0, h->trace_stream, P);
     PT_HIP(hipGetLastError());
     PT_HIP(hipEventRecord(t1, h->trace_stream));
