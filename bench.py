@@ -342,9 +342,9 @@ def main():
         nif_s = agg["nif_ms"] * 1e-3
         achieved = agg["escaped"] * flops / nif_s / 1e12 if nif_s > 0 else 0.0
         wide = args.hidden > 320
-        kernel = ("nifg_layer_kernel<0> (+ encode/head per chunk)" if wide
+        kernel = ("nifg16_layer_kernel<0, 0> (+ encode, the head-fused last layer <1, 0> and the finish kernel per chunk)" if wide
                   else "nif_kernel_v3<%d, 12, 8, %d, 0>" % (args.hidden, 2 if (args.hidden // 32) % 2 == 0 else 1))
-        traffic, traffic_src = hbm_traffic_from_profile("nifg_layer_kernel" if wide else "nif_kernel_v3<%d" % args.hidden)
+        traffic, traffic_src = hbm_traffic_from_profile("nifg16_layer_kernel<0" if wide else "nif_kernel_v3<%d" % args.hidden)
         out = {
             "metric": "Mpath-samples/sec @%dx%d, %d spp/step, depth %d" % (W, H, spp, depth),
             "value": total_samples / elapsed / 1e6,
