@@ -6,17 +6,21 @@
 // appended to the workgroup's region of the NIF queue (ballot + one LDS atomic per wave), so the
 // queue the MFMA kernel reads is dense and no ray state ever goes to HBM.
 //
-// Round 3: two phases per workgroup.  60 % of the camera rays hit nothing and end after ONE
+// Round 3: three phases per workgroup.  60 % of the camera rays hit nothing and end after ONE
 // intersection test; in the round-2 kernel every loop trip therefore re-generated more than half
 // of the wave's lanes -- noise, camera ray, normalisation: the costliest stretch of the kernel --
 // with only those lanes active, and bounced the rest beside them (55 % lane utilisation).  Now a
 // workgroup first runs ALL its camera rays, 64 new paths per wave and trip, every lane active
 // (primary phase: ray generation + first intersection; a miss is final and goes to the queue, a
-// hit leaves an 8-byte note -- path index and the half-rounded camera ray -- in the workgroup's
-// survivor list, which stays in L2), and then bounces the survivors in the persistent loop
-// (secondary phase), where a lane whose path ends is refilled from the list for the price of one
-// load and a normalisation, so the wave stays full.  Same device functions in the same order on
-// the same values: bit-identical paths (tests/test_gpu_parity.py).
+// hit leaves a 16-byte note -- path index, the half-rounded camera ray, hit distance and object --
+// in the workgroup's survivor list: diffuse hits from the front of the list, mirror and glass
+// hits from its back), then shades every survivor's first hit, again 64 per wave and trip and,
+// thanks to the two-ended list, one material at a time (first-shading phase: Philox block, BSDF,
+// 40 bytes of path state into a second list), and only then bounces what is left in the
+// persistent loop (secondary phase), where a lane whose path ends is refilled from the state list
+// for the price of three loads, so the wave stays full.  Both lists are written and read inside
+// the launch and stay in L2.  Same device functions in the same order on the same values:
+// bit-identical paths (tests/test_gpu_parity.py).
 #pragma once
 #include "pt_device_math.h"
 
@@ -61,7 +65,9 @@ struct TraceParams {
   uint32_t* region_count;    // [gridDim.x]
   uint8_t* plen;             // [total_paths] length | escaped<<7
   float* rad_r; float* rad_g; float* rad_b;  // [total_paths] (constant-env mode writes here)
-  uint2* survivors;          // [gridDim.x][region_cap] primary-phase notes: path index, camera ray (two halves)
+  uint4* survivors;          // [gridDim.x][region_cap] primary-phase notes: path index, camera ray (two halves), hit distance, object
+  float4* states;            // [3][gridDim.x][region_cap] path states after the first shading: (o, d.x), (d.yz, T.xy), (T.z, idx)
+  size_t state_stride;       // gridDim.x * region_cap
 };
 
 struct PathState {
@@ -186,6 +192,9 @@ __device__ __forceinline__ void fill_hit_table(const TraceParams& P, HitRow* tab
   }
 }
 
+__device__ __forceinline__ int shade_hit(const TraceParams& P, const HitRow* tab, PathState& s, int best, float tbest,
+                                         const uint32_t (&w)[4], float rr, uint32_t& length);
+
 // One iteration of the while loop of RayTraceKernel::compute (codelets.cpp:173-216) with the
 // AccumulateContributions fold (codelets.cpp:255-292) carried forward as throughput T.
 // Returns the path length (contribution-stack size, codelets.cpp:253) through `length` when the
@@ -209,6 +218,13 @@ __device__ __forceinline__ int bounce(const TraceParams& P, const HitRow* tab, P
     length = s.depth + 1u;
     return STEP_ESCAPED;
   }
+  return shade_hit(P, tab, s, best, tbest, w, rr, length);
+}
+
+// The second half of a loop trip of RayTraceKernel::compute (codelets.cpp:192-216): the ray has hit object `best` at
+// distance `tbest`; w = the bounce's Philox block, rr = its roulette weight.
+__device__ __forceinline__ int shade_hit(const TraceParams& P, const HitRow* tab, PathState& s, int best, float tbest,
+                                         const uint32_t (&w)[4], float rr, uint32_t& length) {
   // the hit object's row, by per-lane index
   const float4 hc = tab[best].centre, hn = tab[best].normal, hcol = tab[best].colour;
   const float cx = hc.x, cy = hc.y, cz = hc.z, nx = hn.x, ny = hn.y, nz = hn.z, cr = hcol.x, cg = hcol.y, cb = hcol.z;
@@ -322,16 +338,20 @@ __device__ __forceinline__ uint32_t pack_half2(float a, float b) {   // both are
 template <uint32_t REFILL>
 __device__ __forceinline__ void trace_body(const TraceParams& P) {
   __shared__ uint32_t wg_count;   // escaped paths queued by this workgroup
-  __shared__ uint32_t wg_surv;    // camera rays of this workgroup that hit something
+  __shared__ uint32_t wg_front, wg_back;   // camera rays of this workgroup that hit a diffuse / a mirror or glass object
+  __shared__ uint32_t wg_state;            // survivors still alive after their first shading
   __shared__ HitRow hit_table[kNumObjects];
-  if (threadIdx.x == 0) { wg_count = 0; wg_surv = 0; fill_hit_table(P, hit_table); }
+  if (threadIdx.x == 0) { wg_count = 0; wg_front = 0; wg_back = 0; wg_state = 0; fill_hit_table(P, hit_table); }
   __syncthreads();
 
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wib = threadIdx.x >> 6;                              // wave in the workgroup
   const uint32_t gw = blockIdx.x * (kTraceBlock / 64) + wib;
   const uint32_t region_base = blockIdx.x * P.region_cap;
-  uint2* const surv = P.survivors + (size_t)region_base;
+  uint4* const surv = P.survivors + (size_t)region_base;
+  float4* const st0 = P.states + (size_t)region_base;
+  float4* const st1 = st0 + P.state_stride;
+  float4* const st2 = st1 + P.state_stride;
   // paths this wave owns: chunk j -> idx = (j * n_waves + gw) * 64 + lane
   const uint32_t n_chunks = (P.total_paths + 63u) / 64u;
   const uint32_t my_chunks = (n_chunks > gw) ? (n_chunks - gw + P.n_waves - 1u) / P.n_waves : 0u;
@@ -341,37 +361,86 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
     const uint32_t idx = (j * P.n_waves + gw) * 64u + lane;
     const bool valid = idx < P.total_paths;
     PathState st;
-    float camx = 0.f, camy = 0.f;
-    bool hit = false;
+    float camx = 0.f, camy = 0.f, tbest = 0.f;
+    int best = -1;
     if (valid) {
       start_path(P, P.pix[idx % P.n_items], P.sample_base + idx / P.n_items, st, camx, camy);
-      float t;
-      hit = nearest_hit(P, st.o, st.d, t) >= 0;
+      best = nearest_hit(P, st.o, st.d, tbest);
     }
+    const bool hit = best >= 0;
     // a miss at depth 0 is final (codelets.cpp:184-190): one record, no roulette below roulette_depth >= 1, so the
     // throughput is (1, 1, 1) x 1 exactly as bounce() would leave it
     const bool escaped = valid && !hit;
     if (escaped) P.plen[idx] = (uint8_t)(1u | 0x80u);
     emit_escaped(P, escaped, st, idx, lane, region_base, &wg_count);
-    const uint64_t hit_mask = __ballot(hit);
-    if (hit_mask) {
+    // survivors: diffuse hits fill the list from the front, mirror / glass hits from the back
+    const bool diffuse = hit && (__float_as_uint(hit_table[hit ? best : 0].colour.w) & 0xffu) == (uint32_t)MAT_DIFFUSE;
+    const bool other = hit && !diffuse;
+    const uint64_t dmask = __ballot(diffuse), omask = __ballot(other);
+    uint32_t pos = 0;
+    if (dmask) {
       uint32_t base = 0;
-      if (lane == (uint32_t)__ffsll((long long)hit_mask) - 1u) base = atomicAdd(&wg_surv, (uint32_t)__popcll(hit_mask));
-      base = __shfl(base, __ffsll((long long)hit_mask) - 1, 64);
-      if (hit) {
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(hit_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hit_mask, 0u));
-        surv[base + rank] = make_uint2(idx, pack_half2(camx, camy));
+      if (lane == (uint32_t)__ffsll((long long)dmask) - 1u) base = atomicAdd(&wg_front, (uint32_t)__popcll(dmask));
+      base = __shfl(base, __ffsll((long long)dmask) - 1, 64);
+      if (diffuse) pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(dmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dmask, 0u));
+    }
+    if (omask) {
+      uint32_t base = 0;
+      if (lane == (uint32_t)__ffsll((long long)omask) - 1u) base = atomicAdd(&wg_back, (uint32_t)__popcll(omask));
+      base = __shfl(base, __ffsll((long long)omask) - 1, 64);
+      if (other) pos = P.region_cap - 1u - (base + __builtin_amdgcn_mbcnt_hi((uint32_t)(omask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)omask, 0u)));
+    }
+    if (hit) surv[pos] = make_uint4(idx, pack_half2(camx, camy), __float_as_uint(tbest), (uint32_t)best);
+  }
+  __syncthreads();   // the workgroup's survivor list is complete (and visible: the workgroup's own global stores, first read now)
+  const uint32_t n_front = wg_front, n_surv = n_front + wg_back;
+
+  // ---- first-shading phase: survivor v of the list (front part, then back part) gets its depth-0 bounce finished -- the half
+  // of a loop trip behind the intersection -- 64 survivors per wave and trip, a chunk inside the front part all diffuse
+  for (uint32_t c = wib; c * 64u < n_surv; c += 4u) {
+    const uint32_t v = c * 64u + lane;
+    const bool valid = v < n_surv;
+    bool alive = false;
+    PathState st;
+    uint32_t idx = 0;
+    if (valid) {
+      const uint4 note = surv[v < n_front ? v : P.region_cap - 1u - (v - n_front)];
+      idx = note.x;
+      union { uint32_t u; _Float16 h[2]; } cam;
+      cam.u = note.y;
+      st.o = mk(0.f, 0.f, 0.f);
+      st.d = normalise(mk((float)cam.h[0], (float)cam.h[1], -1.f));      // as start_path (codelets.cpp:162-163)
+      st.T = mk(1.f, 1.f, 1.f);
+      st.pixel = P.pix[idx % P.n_items];
+      st.sample = P.sample_base + idx / P.n_items;
+      st.depth = 0;
+      uint32_t w[4];
+      philox4x32_10(st.pixel, st.sample, 1u, 0x5054u, P.seed_lo, P.seed_hi, w);   // the block of bounce 0; no roulette at depth 0
+      uint32_t length = 0;
+      const int res = shade_hit(P, hit_table, st, (int)note.w, __uint_as_float(note.z), w, 1.0f, length);
+      if (res == STEP_CONTINUE) alive = true;
+      else P.plen[idx] = (uint8_t)length;                                  // max_path_length = 1: the stack is full
+    }
+    const uint64_t amask = __ballot(alive);
+    if (amask) {
+      uint32_t base = 0;
+      if (lane == (uint32_t)__ffsll((long long)amask) - 1u) base = atomicAdd(&wg_state, (uint32_t)__popcll(amask));
+      base = __shfl(base, __ffsll((long long)amask) - 1, 64);
+      if (alive) {
+        const uint32_t e = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(amask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)amask, 0u));
+        st0[e] = make_float4(st.o.x, st.o.y, st.o.z, st.d.x);
+        st1[e] = make_float4(st.d.y, st.d.z, st.T.x, st.T.y);
+        st2[e] = make_float4(st.T.z, __uint_as_float(idx), 0.f, 0.f);
       }
     }
   }
-  __syncthreads();   // the workgroup's survivor list is complete (and visible: the workgroup's own global stores, first read now)
-  const uint32_t n_surv = wg_surv;
+  __syncthreads();
+  const uint32_t n_state = wg_state;
 
-  // ---- secondary phase: the path loop over the survivors, persistent lanes.  Wave w owns entries
-  // e(j) = ((j / 64) * 4 + w) * 64 + j % 64 of the list; an idle lane takes the next one: camera ray from its two halves,
-  // then bounce() from depth 0 (the first intersection is recomputed: cheaper than carrying its result through memory)
+  // ---- secondary phase: the path loop over the shaded survivors, persistent lanes.  Wave w owns entries
+  // e(j) = ((j / 64) * 4 + w) * 64 + j % 64 of the state list; an idle lane takes the next one and goes on at depth 1.
   uint32_t cursor = 0;
-  const uint32_t s_chunks = (n_surv + 63u) / 64u;
+  const uint32_t s_chunks = (n_state + 63u) / 64u;
   const uint32_t mine = (s_chunks > wib) ? (s_chunks - wib + 3u) / 4u * 64u : 0u;
   PathState st;
   uint32_t idx = 0;
@@ -387,17 +456,15 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
       if (!active) {
         const uint32_t j = cursor + rank;
         const uint32_t e = ((j >> 6) * 4u + wib) * 64u + (j & 63u);
-        if (j < mine && e < n_surv) {
-          const uint2 note = surv[e];
-          idx = note.x;
-          union { uint32_t u; _Float16 h[2]; } c;
-          c.u = note.y;
-          st.o = mk(0.f, 0.f, 0.f);
-          st.d = normalise(mk((float)c.h[0], (float)c.h[1], -1.f));     // as start_path (codelets.cpp:162-163)
-          st.T = mk(1.f, 1.f, 1.f);
+        if (j < mine && e < n_state) {
+          const float4 a = st0[e], b = st1[e], c = st2[e];
+          st.o = mk(a.x, a.y, a.z);
+          st.d = mk(a.w, b.x, b.y);
+          st.T = mk(b.z, b.w, c.x);
+          idx = __float_as_uint(c.y);
           st.pixel = P.pix[idx % P.n_items];
           st.sample = P.sample_base + idx / P.n_items;
-          st.depth = 0;
+          st.depth = 1;
           active = true;
         }
       }

@@ -96,7 +96,8 @@ struct pt_context {
   struct BatchBuffers {
     float *q_u = nullptr, *q_v = nullptr, *q_tr = nullptr, *q_tg = nullptr, *q_tb = nullptr;
     uint32_t* q_path = nullptr;
-    uint2* survivors = nullptr;        // primary-phase notes of the trace kernel, one region per trace workgroup
+    uint4* survivors = nullptr;        // primary-phase notes of the trace kernel, one region per trace workgroup
+    float4* states = nullptr;          // path states after the first shading, three planes of queue_cap float4
     uint32_t* region_count = nullptr;
     uint8_t* plen = nullptr;
     float *rad_r = nullptr, *rad_g = nullptr, *rad_b = nullptr;
@@ -243,12 +244,14 @@ void fill_trace_params(pt_handle h, ptd::TraceParams& P) {
   P.env_const = h->env_const ? 1 : 0;
   P.env_r = h->env_rgb[0]; P.env_g = h->env_rgb[1]; P.env_b = h->env_rgb[2];
   P.pix = h->acc.pix;
+  P.state_stride = h->queue_cap;
 }
 
 void bind_batch(ptd::TraceParams& P, const pt_context::BatchBuffers& B) {
   P.q_u = B.q_u; P.q_v = B.q_v; P.q_tr = B.q_tr; P.q_tg = B.q_tg; P.q_tb = B.q_tb; P.q_path = B.q_path;
   P.region_count = B.region_count;
   P.survivors = B.survivors;
+  P.states = B.states;
   P.plen = B.plen;
   P.rad_r = B.rad_r; P.rad_g = B.rad_g; P.rad_b = B.rad_b;
 }
@@ -950,7 +953,7 @@ int launch_nif(pt_handle h, const ptd::NifParams& N, int blocks) {
 void free_batch_buffers(pt_handle h) {
   for (auto& B : h->bb) {
     (void)hipFree(B.q_u); (void)hipFree(B.q_v); (void)hipFree(B.q_tr); (void)hipFree(B.q_tg); (void)hipFree(B.q_tb);
-    (void)hipFree(B.q_path); (void)hipFree(B.survivors); (void)hipFree(B.region_count); (void)hipFree(B.plen);
+    (void)hipFree(B.q_path); (void)hipFree(B.survivors); (void)hipFree(B.states); (void)hipFree(B.region_count); (void)hipFree(B.plen);
     (void)hipFree(B.rad_r); (void)hipFree(B.rad_g); (void)hipFree(B.rad_b);
     if (B.traced) (void)hipEventDestroy(B.traced);
     if (B.accumulated) (void)hipEventDestroy(B.accumulated);
@@ -1043,6 +1046,7 @@ int pt_create(const pt_config* cfg, pt_handle* out) {
     PT_HIPC(dev_alloc(&B.q_tb, h->queue_cap));
     PT_HIPC(dev_alloc(&B.q_path, h->queue_cap));
     PT_HIPC(dev_alloc(&B.survivors, h->queue_cap));
+    PT_HIPC(dev_alloc(&B.states, 3 * h->queue_cap));
     PT_HIPC(dev_alloc(&B.region_count, (size_t)ptd::kMaxRegions));
     PT_HIPC(dev_alloc(&B.plen, h->batch_paths_cap));
     PT_HIPC(dev_alloc(&B.rad_r, h->batch_paths_cap));
