@@ -46,6 +46,25 @@ std::size_t pth_balance_and_clear(TraceRecord* records, std::size_t n, std::size
   return sum;
 }
 
+// dealTilesByPathLength: owner[t] for every tile; tileWorkList: the padded worklist of one device under that deal.
+void pth_deal_tiles(const unsigned long long* cost, std::size_t n_tiles, std::size_t devices, int* owner_out) {
+  std::vector<std::uint64_t> c(cost, cost + n_tiles);
+  auto owner = dealTilesByPathLength(c, devices);
+  for (std::size_t t = 0; t < n_tiles; ++t) owner_out[t] = owner[t];
+}
+long pth_tile_worklist(std::size_t w, std::size_t h, const int* owner, std::size_t n_tiles, int device, std::size_t pad_to,
+                       TraceRecord* out) {
+  try {
+    std::vector<std::int32_t> o(owner, owner + n_tiles);
+    auto list = tileWorkList(w, h, o, device, pad_to);
+    std::memcpy(out, list.data(), list.size() * sizeof(TraceRecord));
+    return (long)list.size();
+  } catch (const std::exception&) {
+    return -1;
+  }
+}
+std::size_t pth_max_tile_items(std::size_t w, std::size_t h, std::size_t devices) { return maxTileItemsPerDevice(w, h, devices); }
+
 // Accumulate `steps` identical record lists into a film, tone-map, save; copies the HDR (BGR) film out.
 int pth_film_roundtrip(const TraceRecord* records, std::size_t n, std::size_t w, std::size_t h, std::size_t steps, float exposure,
                        float gamma, const char* file, float* hdr_out, unsigned char* ldr_out) {

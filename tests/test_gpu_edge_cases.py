@@ -220,3 +220,46 @@ def test_failed_path_trace_drains_and_the_handle_stays_usable(oracle, ptmi_lib):
     for c in "rgb":
         np.testing.assert_allclose(rec[c], ref[c], rtol=2e-2, atol=1e-6)
     r.close()
+
+
+def test_tile_costs_and_film_seed_contract(ptmi_lib):
+    """pt_tile_costs / pt_film_seed argument checks and semantics: costs need pt_tile_costs_enable and the grid's exact size;
+    padding items belong to no tile; pt_setup starts the sums afresh; a seeded film is what the gather returns and what
+    later steps add to."""
+    W, H = 40, 24                                                              # 3 x 2 tiles of 16 x 16
+    r = ptmi_lib.Renderer(W, H, max_path_length=5, max_work_items=W * H + 7)
+    r.set_constant_env((1.0, 1.0, 1.0))
+    r.init_render_settings(samples_per_step=3)
+    rec = np.zeros(W * H + 7, dtype=ptmi_lib.TRACE_DTYPE)
+    rec[: W * H] = ptmi_lib.worklist(W, H)
+    rec["u"][W * H:] = 65535
+    rec["v"][W * H:] = 65535                                                   # padding items (LoadBalancer.cpp:66-71)
+    r.setup(rec)
+    lib = ptmi_lib.load_library()
+    out = np.zeros(6, dtype=np.uint64)
+    assert lib.pt_tile_costs(r.handle, out.ctypes.data, 6) == -5               # PT_ERR_NOT_READY: not enabled
+    with pytest.raises(ptmi_lib.PtError):
+        r.tile_costs_enable(0, 16)
+    r.tile_costs_enable(16, 16)
+    assert lib.pt_tile_costs(r.handle, out.ctypes.data, 5) == -1               # wrong grid size
+    r.path_trace()
+    got = r.read_results(rec)
+    costs = r.tile_costs(W, H)
+    real = rec[: W * H]
+    t = (real["v"].astype(np.int64) // 16) * 3 + real["u"].astype(np.int64) // 16
+    np.testing.assert_array_equal(costs, np.bincount(t, weights=real["pathLength"], minlength=6).astype(np.uint64))
+    assert costs.sum() == got.segments - int(rec["pathLength"][W * H:].sum())  # the padding items' paths are in no tile
+    r.setup(rec)
+    assert not r.tile_costs(W, H).any()                                        # a new worklist starts new sums
+    # film seed: exactly the current items, then the film is seed + the steps' means
+    seed = np.arange(rec.size * 3, dtype=np.float32).reshape(-1, 3)
+    with pytest.raises(ptmi_lib.PtError):
+        r.film_seed(seed[:-1])
+    r.film_seed(seed)
+    np.testing.assert_array_equal(r.gather_hdr(rec.size, source=ptmi_lib.HDR_FILM)[0], seed)
+    r.path_trace()
+    r.read_results(rec)
+    mean = np.stack([rec["b"], rec["g"], rec["r"]], -1) * (np.float32(1.0) / rec["sampleCount"].astype(np.float32))[:, None]
+    r.film_accumulate()
+    np.testing.assert_array_equal(r.gather_hdr(rec.size, source=ptmi_lib.HDR_FILM)[0], seed + mean)
+    r.close()

@@ -105,6 +105,42 @@ def test_balance_is_a_permutation_for_any_item_count(host, n, jobs):
     assert sorted(rec["pathLength"].tolist()) == sorted(before["pathLength"].tolist())
 
 
+def test_tile_dealing_matches_the_python_partition(host):
+    """The C++ host's balancer across devices (dealTilesByPathLength / tileWorkList, the multi-GPU form of
+    LoadBalancer::allocateWorkByPathLength, LoadBalancer.cpp:141-192) and partition.py derive the same deal and the same
+    worklists: a render driven by `ipu_trace --ipus N` and one driven by N Python ranks place every pixel alike."""
+    from ipu_path_trace_amd import partition
+    W, H = 200, 136                                             # 13 x 9 tiles of 16 x 16, ragged right and bottom edges
+    n_tiles = int(np.prod(partition.tile_grid(W, H)))
+    rng = np.random.default_rng(11)
+    cost = rng.integers(0, 5000, n_tiles).astype(np.uint64)
+    cost[rng.integers(0, n_tiles, 20)] = 777                    # ties: broken by tile id on both sides
+    host.pth_deal_tiles.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]
+    host.pth_tile_worklist.argtypes = [C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_void_p]
+    host.pth_tile_worklist.restype = C.c_long
+    host.pth_max_tile_items.argtypes = [C.c_size_t] * 3
+    host.pth_max_tile_items.restype = C.c_size_t
+    for devices in (1, 2, 3, 8):
+        owner = np.zeros(n_tiles, dtype=np.int32)
+        host.pth_deal_tiles(cost.ctypes.data, n_tiles, devices, owner.ctypes.data)
+        np.testing.assert_array_equal(owner, partition.deal_by_path_length(cost, devices))
+        cap = host.pth_max_tile_items(W, H, devices)
+        assert cap == partition.max_items_per_rank(W, H, devices)
+        seen = np.zeros((H, W), dtype=np.int32)
+        for d in range(devices):
+            rec = np.zeros(cap, dtype=TRACE_DTYPE)
+            assert host.pth_tile_worklist(W, H, owner.ctypes.data, n_tiles, d, cap, rec.ctypes.data) == cap
+            ref = partition.worklist_for_owner(W, H, owner, d)
+            assert rec[: ref.size].tobytes() == ref.tobytes()
+            assert (rec["u"][ref.size:] == 65535).all() and (rec["v"][ref.size:] == 65535).all()      # padding items
+            seen[ref["v"], ref["u"]] += 1
+        assert (seen == 1).all()
+    # a deal that does not fit the capacity is refused, not truncated
+    owner = np.zeros(n_tiles, dtype=np.int32)
+    rec = np.zeros(16, dtype=TRACE_DTYPE)
+    assert host.pth_tile_worklist(W, H, owner.ctypes.data, n_tiles, 0, 16, rec.ctypes.data) == -1
+
+
 def test_ipu_path_trace_job_interface(host):
     """IpuPathTraceJob(maxRayCount, args, core), buildGraph, beginTraceJob/endTraceJob, splitTilePixelsOverWorkers
     (IpuPathTraceJob.hpp:43-54, IpuPathTraceJob.cpp:30-52,95-138)."""
