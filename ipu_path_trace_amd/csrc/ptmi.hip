@@ -19,6 +19,7 @@
 #include "ptmi.h"
 #include "pt_nif.h"
 #include "pt_nif_gemm.h"
+#include "pt_nif_f32.h"
 #ifdef PTMI_DIAG_BUILD
 #include "diag/pt_nif_gemm32.h"
 #include "diag/pt_nif16.h"
@@ -122,6 +123,14 @@ struct pt_context {
   int nif_hidden = 0, nif_emb = 0;   // PADDED hidden width / embedding dimension the kernels are instantiated for
   bool nif_gemm = false;  // layer-by-layer path (pt_nif_gemm.h)
   bool nif_gemm32 = false;   // profiling build: the round-2 32x32x16 layer kernels (diag/pt_nif_gemm32.h) for the A/B
+  // float32 models (pt_nif_f32.h): padded row-major kernels and biases of all layers in one buffer, chunk buffers
+  bool nif_f32 = false;
+  struct F32Layer { size_t w_off, b_off; uint32_t k_act, k_in, ldw, relu; };
+  std::vector<F32Layer> f32_layers;
+  float* d_f32_weights = nullptr;
+  float* d_f32_act[2] = {nullptr, nullptr};
+  float* d_f32_feat = nullptr;
+  uint32_t f32_chunk = 0, f32_lda = 0, f32_ldf = 0;
   float4* d_head_partial = nullptr;   // fused head: [2 FB][chunk samples] partial sums
   float4* d_head_in = nullptr;        // head weights of the Fourier-feature inputs [4][E], if the head concatenates them
   float head_bias[3] = {0, 0, 0};
@@ -927,7 +936,114 @@ int launch_nif_gemm(pt_handle h, const ptd::NifParams& N) {
   return PT_OK;
 }
 
+// ---- float32 models (pt_nif_f32.h) -----------------------------------------------------------------------------
+// Shapes as normalize_nif: hidden widths padded to a common multiple of 32 (zero weights, zero bias), the Fourier features
+// to 4 x Ep with Ep = E rounded up to a multiple of 4 (zero rows for the padding slots, zero features).
+struct HostLayerF32 { uint32_t rows, cols; std::vector<float> kernel, bias; bool has_bias, relu; };
+
+int pack_nif_f32(pt_handle h, const std::vector<HostLayerF32>& L, uint32_t E, std::vector<float>& blob,
+                 std::vector<pt_context::F32Layer>& out, uint32_t& Hp_out, uint32_t& Ep_out) {
+  const uint32_t n = (uint32_t)L.size();
+  if (n < 2 || n > ptd::kMaxLayers) return fail(h, PT_ERR_UNSUPPORTED_MODEL, "NIF must have 2..16 dense layers");
+  if (E == 0 || E > 16) return fail(h, PT_ERR_UNSUPPORTED_MODEL, "embedding dimension must be in 1..16");
+  const uint32_t in_dim = 4 * E, Ep = (E + 3u) / 4u * 4u, in_p = 4 * Ep;
+  if (L[0].rows != in_dim) return fail(h, PT_ERR_UNSUPPORTED_MODEL, "first layer must take the 4*embedding Fourier features");
+  if (L[n - 1].cols != 3) return fail(h, PT_ERR_UNSUPPORTED_MODEL, "NIF head must have 3 outputs (BGR)");
+  uint32_t widest = 0;
+  for (uint32_t l = 0; l + 1 < n; ++l) widest = std::max(widest, L[l].cols);
+  const uint32_t Hp = (widest + 31u) / 32u * 32u;
+  if (Hp > kMaxGemmHidden) return fail(h, PT_ERR_UNSUPPORTED_MODEL, "hidden layers wider than 2048 are not supported");
+  out.clear();
+  blob.clear();
+  uint32_t prev = 0;
+  for (uint32_t l = 0; l < n; ++l) {
+    const HostLayerF32& Y = L[l];
+    const bool head = l + 1 == n;
+    bool concat = false;
+    if (l == 0) {
+    } else if (Y.rows == prev) {
+    } else if (Y.rows == prev + in_dim) {   // NifModel.cpp:305-308
+      concat = true;
+    } else {
+      return fail(h, PT_ERR_UNSUPPORTED_MODEL, "layer " + std::to_string(l) + ": input width " + std::to_string(Y.rows) +
+                                                   " is neither the previous layer's width nor that plus the 4*embedding features");
+    }
+    pt_context::F32Layer F{};
+    F.k_act = l ? Hp : 0u;
+    F.k_in = (l == 0 || concat) ? in_p : 0u;
+    F.ldw = head ? 4u : Hp;
+    F.relu = Y.relu;
+    F.w_off = blob.size();
+    blob.resize(blob.size() + (size_t)(F.k_act + F.k_in) * F.ldw, 0.f);
+    float* W = &blob[F.w_off];
+    const uint32_t act_t = l ? prev : 0u;
+    for (uint32_t r = 0; r < act_t; ++r)
+      for (uint32_t c = 0; c < Y.cols; ++c) W[(size_t)r * F.ldw + c] = Y.kernel[(size_t)r * Y.cols + c];
+    if (F.k_in)
+      for (uint32_t f = 0; f < in_dim; ++f)   // feature order [sin u, sin v, cos u, cos v] x E (NifModel.cpp:216)
+        for (uint32_t c = 0; c < Y.cols; ++c)
+          W[(size_t)(F.k_act + (f / E) * Ep + (f % E)) * F.ldw + c] = Y.kernel[(size_t)(act_t + f) * Y.cols + c];
+    F.b_off = blob.size();
+    blob.resize(blob.size() + F.ldw, 0.f);
+    if (Y.has_bias) for (uint32_t c = 0; c < Y.cols; ++c) blob[F.b_off + c] = Y.bias[c];
+    blob.resize((blob.size() + 3) / 4 * 4, 0.f);   // keep every kernel 16-byte aligned (the head reads float4 rows)
+    out.push_back(F);
+    prev = Y.cols;
+  }
+  Hp_out = Hp;
+  Ep_out = Ep;
+  return PT_OK;
+}
+
+template <int E>
+void launch_nif32_encode(pt_handle h, const ptd::NifParams& N, uint32_t tile0, uint32_t chunk) {
+  hipLaunchKernelGGL((ptd::nif32_encode_kernel<E>), dim3((chunk + 3u) / 4u), dim3(256), 0, h->stream, N, h->d_tile_start, tile0, chunk,
+                     h->d_f32_feat);
+}
+
+int launch_nif_f32(pt_handle h, const ptd::NifParams& N) {
+  const uint32_t chunk = h->f32_chunk, n_layers = (uint32_t)h->f32_layers.size();
+  if (!chunk) return fail(h, PT_ERR_NOT_READY, "float32 NIF buffers are not allocated");
+  hipLaunchKernelGGL(ptd::nifg_scan_kernel, dim3(1), dim3(256), 0, h->stream, N.region_count, N.n_regions, h->d_tile_start);
+  PT_HIP(hipGetLastError());
+  const uint64_t max_tiles = (uint64_t)N.n_regions * ((N.region_cap + 31u) / 32u);
+  for (uint64_t tile0 = 0; tile0 < max_tiles; tile0 += chunk) {
+    switch (h->nif_emb) {
+      case 4: launch_nif32_encode<4>(h, N, (uint32_t)tile0, chunk); break;
+      case 8: launch_nif32_encode<8>(h, N, (uint32_t)tile0, chunk); break;
+      case 12: launch_nif32_encode<12>(h, N, (uint32_t)tile0, chunk); break;
+      case 16: launch_nif32_encode<16>(h, N, (uint32_t)tile0, chunk); break;
+      default: return fail(h, PT_ERR_UNSUPPORTED_MODEL, "unsupported embedding dimension");
+    }
+    PT_HIP(hipGetLastError());
+    for (uint32_t l = 0; l < n_layers; ++l) {
+      const pt_context::F32Layer& F = h->f32_layers[l];
+      const float* in = h->d_f32_act[(l + 1u) & 1u];
+      if (l + 1 < n_layers) {
+        ptd::NifF32Params G{};
+        G.w = h->d_f32_weights + F.w_off; G.bias = h->d_f32_weights + F.b_off;
+        G.ldw = F.ldw; G.k_act = F.k_act; G.k_in = F.k_in; G.relu = F.relu;
+        G.act_in = in; G.feat = h->d_f32_feat; G.act_out = h->d_f32_act[l & 1u];
+        G.lda = h->f32_lda; G.ldf = h->f32_ldf;
+        G.total_tiles = h->d_tile_start + N.n_regions; G.tile0 = (uint32_t)tile0; G.chunk_tiles = chunk;
+        hipLaunchKernelGGL(ptd::nif32_layer_kernel, dim3(chunk / 4u, F.ldw / 32u), dim3(256), 0, h->stream, G);
+      } else {
+        ptd::NifF32Head Hd{};
+        Hd.w = h->d_f32_weights + F.w_off;
+        Hd.k_act = F.k_act; Hd.k_in = F.k_in; Hd.relu = F.relu;
+        Hd.bias0 = h->head_bias[0]; Hd.bias1 = h->head_bias[1]; Hd.bias2 = h->head_bias[2];
+        Hd.act_in = in; Hd.feat = h->d_f32_feat; Hd.lda = h->f32_lda; Hd.ldf = h->f32_ldf;
+        Hd.tile0 = (uint32_t)tile0; Hd.chunk_tiles = chunk;
+        hipLaunchKernelGGL(ptd::nif32_head_kernel, dim3((chunk + 7u) / 8u), dim3(256), 0, h->stream, N, Hd, h->d_tile_start);
+      }
+      PT_HIP(hipGetLastError());
+    }
+  }
+  return PT_OK;
+}
+
 int launch_nif(pt_handle h, const ptd::NifParams& N, int blocks) {
+  if (h->nif_f32) return launch_nif_f32(h, N);
   if (h->nif_gemm) {
 #ifdef PTMI_DIAG_BUILD
     // A/B switch of the profiling build: the fused 64-sample kernel with activations in LDS
@@ -1077,6 +1193,7 @@ int pt_destroy(pt_handle h) {
   (void)hipFree(h->d_gemm_act[0]); (void)hipFree(h->d_gemm_act[1]); (void)hipFree(h->d_gemm_feat); (void)hipFree(h->d_tile_start);
   (void)hipFree(h->d_stamps);
   (void)hipFree(h->d_head_partial); (void)hipFree(h->d_head_in);
+  (void)hipFree(h->d_f32_weights); (void)hipFree(h->d_f32_act[0]); (void)hipFree(h->d_f32_act[1]); (void)hipFree(h->d_f32_feat);
   (void)hipFree(h->d_scratch);
   (void)hipFree(h->d_hdr_stage); (void)hipFree(h->d_hdr_gather); (void)hipFree(h->d_film);
   (void)hipFree(h->d_slot_check);
@@ -1090,16 +1207,78 @@ int pt_destroy(pt_handle h) {
   return PT_OK;
 }
 
+// A model all of whose layers are float32: the float path (pt_nif_f32.h).
+static int upload_nif_f32(pt_handle h, const pt_layer* layers, uint32_t n_layers, uint32_t embedding_dim, float max,
+                          const float mean[3], int32_t log_tonemap) {
+  std::vector<HostLayerF32> L(n_layers);
+  uint64_t flops = 0;
+  for (uint32_t l = 0; l < n_layers; ++l) {
+    L[l].rows = layers[l].rows; L[l].cols = layers[l].cols; L[l].relu = layers[l].relu != 0; L[l].has_bias = layers[l].bias != nullptr;
+    const float* kp = static_cast<const float*>(layers[l].kernel);
+    L[l].kernel.assign(kp, kp + (size_t)L[l].rows * L[l].cols);
+    if (layers[l].bias) { const float* bp = static_cast<const float*>(layers[l].bias); L[l].bias.assign(bp, bp + L[l].cols); }
+    flops += 2ull * L[l].rows * L[l].cols + (layers[l].bias ? L[l].cols : 0);  // NifModel.cpp:129-133
+  }
+  std::vector<float> blob;
+  std::vector<pt_context::F32Layer> F;
+  uint32_t Hp = 0, Ep = 0;
+  if (int rc = pack_nif_f32(h, L, embedding_dim, blob, F, Hp, Ep)) return rc;
+  PT_HIP(hipSetDevice(h->cfg.device));
+  PT_HIP(hipStreamSynchronize(h->stream));
+  h->nif_valid = false;
+  const uint32_t chunk = 1024;   // queue tiles per chunk (32,768 samples): 2 x 42 MB of activations at width 320
+  for (float** p : {&h->d_f32_weights, &h->d_f32_act[0], &h->d_f32_act[1], &h->d_f32_feat}) {
+    if (*p) PT_HIP(hipFree(*p));
+    *p = nullptr;
+  }
+  h->f32_chunk = 0;
+  PT_HIP(dev_alloc(&h->d_f32_weights, blob.size()));
+  PT_HIP(hipMemcpy(h->d_f32_weights, blob.data(), blob.size() * 4, hipMemcpyHostToDevice));
+  PT_HIP(dev_alloc(&h->d_f32_act[0], (size_t)chunk * 32 * Hp));
+  PT_HIP(dev_alloc(&h->d_f32_act[1], (size_t)chunk * 32 * Hp));
+  PT_HIP(dev_alloc(&h->d_f32_feat, (size_t)chunk * 32 * 4 * Ep));
+  if (!h->d_tile_start) PT_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_tile_start), (ptd::kMaxRegions + 1) * 4));
+  const HostLayerF32& head = L[n_layers - 1];
+  for (int o = 0; o < 3; ++o) h->head_bias[o] = head.has_bias ? head.bias[o] : 0.f;
+  ptd::NifParams N;
+  memset(&N, 0, sizeof(N));
+  N.n_layers = n_layers;
+  N.n_freq = embedding_dim;
+  N.max = max;
+  N.mean0 = mean[0]; N.mean1 = mean[1]; N.mean2 = mean[2];
+  N.log_tonemap = log_tonemap;
+  h->nif = N;
+  h->f32_layers = F;
+  h->f32_chunk = chunk;
+  h->f32_lda = Hp;
+  h->f32_ldf = 4 * Ep;
+  h->nif_hidden = (int)Hp;
+  h->nif_emb = (int)Ep;
+  h->nif_f32 = true;
+  h->nif_gemm = false;
+  h->nif_gemm32 = false;
+  h->nif_m16 = false;
+  h->nif_flops = flops;
+  h->nif_valid = true;
+  h->env_const = false;
+  return PT_OK;
+}
+
 int pt_upload_nif(pt_handle h, const pt_layer* layers, uint32_t n_layers, uint32_t embedding_dim, float max,
                   const float mean[3], int32_t log_tonemap) {
   if (!h) return PT_ERR_INVALID_ARGUMENT;
   if (!layers || !mean || n_layers == 0) return fail(h, PT_ERR_INVALID_ARGUMENT, "null NIF arguments");
   std::vector<HostLayer> L(n_layers);
   uint64_t flops = 0;
+  bool all_f32 = true;
   for (uint32_t l = 0; l < n_layers; ++l) {
     if (layers[l].dtype != PT_DTYPE_F16 && layers[l].dtype != PT_DTYPE_F32)
       return fail(h, PT_ERR_UNSUPPORTED_MODEL, "NIF weights must be float16 or float32");
     if (!layers[l].kernel || layers[l].rows == 0 || layers[l].cols == 0) return fail(h, PT_ERR_INVALID_ARGUMENT, "empty layer kernel");
+    all_f32 = all_f32 && layers[l].dtype == PT_DTYPE_F32;
+  }
+  if (all_f32) return upload_nif_f32(h, layers, n_layers, embedding_dim, max, mean, log_tonemap);
+  for (uint32_t l = 0; l < n_layers; ++l) {
     L[l].rows = layers[l].rows;
     L[l].cols = layers[l].cols;
     L[l].relu = layers[l].relu != 0;
@@ -1112,8 +1291,8 @@ int pt_upload_nif(pt_handle h, const pt_layer* layers, uint32_t n_layers, uint32
         L[l].bias.assign(bp, bp + L[l].cols);
       }
     } else {
-      // float32 H5 weights (Hdf5Model.cpp:109-133 accepts them; the reference then runs the layer in float): rounded to
-      // binary16 (RNE) here, the MFMA path computes in fp16 with fp32 accumulation -- DESIGN.md section 2, "fp32 weights"
+      // a float32 layer inside a float16 model (the reference would run that one layer in float; a model all of whose
+      // layers are float32 takes the float path, upload_nif_f32): rounded to binary16 (RNE) here -- DESIGN.md section 2
       const float* kp = static_cast<const float*>(layers[l].kernel);
       L[l].kernel.resize(count);
       for (size_t i = 0; i < count; ++i) L[l].kernel[i] = host_f2h(kp[i]);
@@ -1205,6 +1384,7 @@ int pt_upload_nif(pt_handle h, const pt_layer* layers, uint32_t n_layers, uint32
   h->nif = N;
   h->nif_hidden = (int)plan.Hp;
   h->nif_emb = (int)plan.Ep;
+  h->nif_f32 = false;
   h->nif_gemm = plan.gemm;
   h->nif_gemm32 = gemm32;
   h->nif_m16 = m16;

@@ -590,6 +590,7 @@ struct orc_nif {
   float** bias;
   float max; float mean[3]; int32_t log_tonemap;
   uint32_t max_width;
+  int32_t f32;                   /* float32 model: layers run in float (NifModel.cpp:314, kernel type = output type) */
 };
 
 orc_nif* orc_nif_create(const orc_layer* layers, uint32_t n_layers, uint32_t emb, float max,
@@ -611,6 +612,29 @@ orc_nif* orc_nif_create(const orc_layer* layers, uint32_t n_layers, uint32_t emb
     m->bias[l] = (float*)calloc(c, 4);
     m->has_bias[l] = layers[l].bias != NULL;
     if (layers[l].bias) for (uint32_t i = 0; i < c; ++i) m->bias[l][i] = orc_h2f(layers[l].bias[i]);
+  }
+  return m;
+}
+
+orc_nif* orc_nif_create_f32(const orc_layer_f32* layers, uint32_t n_layers, uint32_t emb, float max,
+                            const float mean[3], int32_t log_tonemap) {
+  orc_nif* m = (orc_nif*)calloc(1, sizeof(orc_nif));
+  m->n_layers = n_layers; m->emb = emb; m->max = max; m->log_tonemap = log_tonemap; m->f32 = 1;
+  memcpy(m->mean, mean, 12);
+  m->rows = calloc(n_layers, 4); m->cols = calloc(n_layers, 4);
+  m->relu = calloc(n_layers, 4); m->has_bias = calloc(n_layers, 4);
+  m->kernel = calloc(n_layers, sizeof(float*)); m->bias = calloc(n_layers, sizeof(float*));
+  m->max_width = 4 * emb;
+  for (uint32_t l = 0; l < n_layers; ++l) {
+    uint32_t r = layers[l].rows, c = layers[l].cols;
+    m->rows[l] = r; m->cols[l] = c; m->relu[l] = layers[l].relu;
+    if (r > m->max_width) m->max_width = r;
+    if (c > m->max_width) m->max_width = c;
+    m->kernel[l] = (float*)malloc((size_t)r * c * 4);
+    memcpy(m->kernel[l], layers[l].kernel, (size_t)r * c * 4);
+    m->bias[l] = (float*)calloc(c, 4);
+    m->has_bias[l] = layers[l].bias != NULL;
+    if (layers[l].bias) memcpy(m->bias[l], layers[l].bias, (size_t)c * 4);
   }
   return m;
 }
@@ -681,8 +705,8 @@ static void nif_forward(const orc_nif* m, const float* u, const float* v, int B,
         }
       }
       for (int b = 0; b < B; ++b) for (uint32_t n = 0; n < nn; ++n) {
-        float o = hround(acc[b][n]);                    /* matmul output type = kernel type (half) */
-        if (m->has_bias[l]) o = hround(o + m->bias[l][n0 + n]);           /* addInPlace :316-321 */
+        float o = m->f32 ? acc[b][n] : hround(acc[b][n]);   /* matmul output type = kernel type (:314) */
+        if (m->has_bias[l]) o = m->f32 ? o + m->bias[l][n0 + n] : hround(o + m->bias[l][n0 + n]);   /* addInPlace :316-321 */
         if (m->relu[l] && !(o > 0.f)) o = 0.f;          /* ReLU :323-325 */
         y[(size_t)b * W + n0 + n] = o;
       }

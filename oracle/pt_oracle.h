@@ -67,6 +67,15 @@ typedef struct {
   int32_t relu;                  /* activation == "relu" (NifModel.cpp:323-325) */
 } orc_layer;
 
+/* The same for a model stored as float32 (Hdf5Model.cpp:109-133 accepts float32 variables): the reference gives the
+ * matmul the kernel's type (NifModel.cpp:314), so such a model runs in float -- no rounding to half between the layers. */
+typedef struct {
+  uint32_t rows, cols;
+  const float* kernel;
+  const float* bias;
+  int32_t relu;
+} orc_layer_f32;
+
 typedef struct orc_nif orc_nif;
 
 typedef struct {
@@ -87,6 +96,8 @@ typedef struct {
 /* ---- NIF (NifModel.cpp:185-245,295-326) ---- */
 orc_nif* orc_nif_create(const orc_layer* layers, uint32_t n_layers, uint32_t embedding_dim,
                         float max, const float mean_folded[3], int32_t log_tonemap);
+orc_nif* orc_nif_create_f32(const orc_layer_f32* layers, uint32_t n_layers, uint32_t embedding_dim,
+                            float max, const float mean[3], int32_t log_tonemap);
 void orc_nif_destroy(orc_nif*);
 /* u,v -> bgr (decoded).  Also the streamed-IO standalone mode of NifModel.cpp:268-278. */
 int orc_nif_infer(const orc_nif*, const float* u, const float* v, size_t n, float* bgr);

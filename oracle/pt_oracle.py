@@ -73,6 +73,8 @@ def lib():
         fp = C.POINTER(C.c_float)
         L.orc_nif_create.restype = C.c_void_p
         L.orc_nif_create.argtypes = [C.POINTER(Layer), C.c_uint32, C.c_uint32, C.c_float, fp, C.c_int32]
+        L.orc_nif_create_f32.restype = C.c_void_p
+        L.orc_nif_create_f32.argtypes = [C.POINTER(Layer), C.c_uint32, C.c_uint32, C.c_float, fp, C.c_int32]
         L.orc_nif_destroy.argtypes = [C.c_void_p]
         L.orc_nif_infer.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.orc_nif_encode.argtypes = [C.c_uint32, C.c_float, C.c_float, C.c_void_p]
@@ -135,23 +137,28 @@ def make_config(width=256, height=256, max_path_length=10, roulette_depth=3, sto
 
 
 class Nif:
-    """Owns an orc_nif built from (kernel fp16 [in,out], bias fp16 [out] | None, relu) triples."""
+    """Owns an orc_nif built from (kernel [in,out], bias [out] | None, relu) triples.  A model ALL of whose kernels are
+    float32 runs in float (the reference gives a matmul its kernel's type, NifModel.cpp:314); anything else is a float16
+    model (float32 entries are rounded to binary16, as the device library does for a float32 layer inside a float16 model)."""
 
     def __init__(self, layers, embedding_dim, max_value, mean_folded, log_tonemap=True):
         self._keep = []
         arr = (Layer * len(layers))()
+        self.float32 = all(np.asarray(k).dtype == np.float32 for k, _, _ in layers)
+        dt = np.float32 if self.float32 else np.float16
         for i, (k, b, relu) in enumerate(layers):
-            k = np.ascontiguousarray(k, dtype=np.float16)
+            k = np.ascontiguousarray(k, dtype=dt)
             self._keep.append(k)
             arr[i].rows, arr[i].cols = k.shape
             arr[i].kernel = k.ctypes.data
             if b is not None:
-                b = np.ascontiguousarray(b, dtype=np.float16)
+                b = np.ascontiguousarray(b, dtype=dt)
                 self._keep.append(b)
                 arr[i].bias = b.ctypes.data
             arr[i].relu = int(bool(relu))
         mean = (C.c_float * 3)(*[float(x) for x in mean_folded])
-        self.handle = lib().orc_nif_create(arr, len(layers), embedding_dim, float(max_value), mean, int(log_tonemap))
+        create = lib().orc_nif_create_f32 if self.float32 else lib().orc_nif_create
+        self.handle = create(arr, len(layers), embedding_dim, float(max_value), mean, int(log_tonemap))
         self.embedding_dim = embedding_dim
 
     def __del__(self):

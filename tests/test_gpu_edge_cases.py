@@ -249,6 +249,10 @@ def test_tile_costs_and_film_seed_contract(ptmi_lib):
     t = (real["v"].astype(np.int64) // 16) * 3 + real["u"].astype(np.int64) // 16
     np.testing.assert_array_equal(costs, np.bincount(t, weights=real["pathLength"], minlength=6).astype(np.uint64))
     assert costs.sum() == got.segments - int(rec["pathLength"][W * H:].sum())  # the padding items' paths are in no tile
+    r.setup(rec)                                                               # accumulators carried in are kept (as in the reference) ...
+    np.testing.assert_array_equal(r.tile_costs(W, H), costs)                   # ... so their path lengths still count, once
+    for c in ("r", "g", "b", "sampleCount", "pathLength"):
+        rec[c] = 0
     r.setup(rec)
     assert not r.tile_costs(W, H).any()                                        # a new worklist starts new sums
     # film seed: exactly the current items, then the film is seed + the steps' means

@@ -72,25 +72,72 @@ def test_bias_free_and_linear_layers(oracle, ptmi_lib):
     _check(oracle, ptmi_lib, L, 8)
 
 
-def test_float32_weights_are_rounded_to_half_on_upload(oracle, ptmi_lib):
-    """A Keras H5 with float32 variables loads (Hdf5Model.cpp:109-133).  The reference would then run float layers;
-    here the kernels are RNE-rounded to binary16 on upload, so the result is bit-identical to uploading the rounded
-    weights, and within the stated tolerance of the oracle evaluated on the rounded weights."""
-    L32 = nif_assets.synthetic_nif(hidden=320, layer_count=6, seed=5, dtype=np.float32)
-    assert L32[0][0].dtype == np.float32
-    L16 = [(k.astype(np.float16), b.astype(np.float16), relu) for k, b, relu in L32]
+@pytest.mark.parametrize("widths,emb,skips", [
+    ([320] * 6, 12, None),                        # the shipped architecture with float32 variables
+    ([96, 72, 40], 10, {2, 3}),                   # ragged widths, embedding not a multiple of 4, concat on a hidden layer and the head
+    ([512, 512], 4, {1}),                         # wider than the register-resident fp16 kernels take
+])
+def test_float32_models_run_in_float(oracle, ptmi_lib, widths, emb, skips):
+    """A Keras H5 with float32 variables loads (Hdf5Model.cpp:109-133) and the reference then gives every matmul its kernel's
+    type (NifModel.cpp:314): the layers run in float.  Rounds 1-2 rounded such weights to binary16; now a model all of whose
+    layers are float32 takes the float path (pt_nif_f32.h: v_mfma_f32_32x32x2_f32, an exact fp32 FMA chain in k order), checked
+    against the oracle's float mode -- the same sequential fmaf sums, so the only differences left are the half-precision
+    trig of the features (v_sin against libm, then rounded to half) and the final exp.  It must NOT equal the fp16 result."""
+    L32 = nif_assets.synthetic_nif(widths=widths, embedding_dim=emb, seed=5, dtype=np.float32, skips=skips)
+    assert all(k.dtype == np.float32 for k, _, _ in L32)
     mean = nif_assets.folded_mean()
+    onif = oracle.Nif(L32, emb, META["max"], mean)
+    assert onif.float32
     rng = np.random.default_rng(1)
-    u = rng.random(5000, dtype=np.float32)
-    v = rng.random(5000, dtype=np.float32)
     r = ptmi_lib.Renderer(64, 64)
+    r.init_nif_weights(L32, emb, META["max"], mean)
+    for n in (1, 33, 5000):
+        u = rng.random(n, dtype=np.float32)
+        v = rng.random(n, dtype=np.float32)
+        got, ref = r.nif_infer(u, v), onif.infer(u, v)
+        assert np.isfinite(got).all()
+        rel = np.abs(got - ref) / np.abs(ref)
+        assert rel.max() < NIF_RTOL_MAX, (n, rel.max())           # a feature one half-ulp off moves the output by this much at most
+        if n > 100:
+            assert np.median(rel) < 2e-5, np.median(rel)          # ... and most samples agree to fp32 rounding
+    L16 = [(k.astype(np.float16), b.astype(np.float16), relu) for k, b, relu in L32]
+    r.init_nif_weights(L16, emb, META["max"], mean)
+    half = r.nif_infer(u, v)
+    r.close()
+    assert np.median(np.abs(half - got) / np.abs(got)) > 1e-4     # the float path is not the fp16 path
+
+
+def test_float32_model_renders_and_a_mixed_model_is_rounded(oracle, ptmi_lib):
+    """The float path inside the whole step (queue, chunks, scatter, accumulate) against the oracle's float mode; and a
+    float32 layer inside a float16 model is rounded to binary16 on upload (documented in include/ptmi.h): bit-identical
+    to uploading the rounded weights."""
+    O = oracle
+    W = H = 48
+    L32 = nif_assets.synthetic_nif(hidden=64, layer_count=3, seed=8, dtype=np.float32)
+    mean = nif_assets.folded_mean()
+    r = ptmi_lib.Renderer(W, H, max_path_length=5)
     r.init_nif_weights(L32, 12, META["max"], mean)
-    a = r.nif_infer(u, v)
+    r.init_render_settings(samples_per_step=3)
+    rec = ptmi_lib.worklist(W, H)
+    r.setup(rec)
+    r.path_trace()
+    st = r.read_results(rec)
+    cfg = O.make_config(width=W, height=H, max_path_length=5, env_mode=O.ENV_NIF)
+    ref = O.worklist(W, H)
+    ost = O.render(cfg, O.Nif(L32, 12, META["max"], mean), ref, 0, 3)
+    assert np.array_equal(rec["pathLength"], ref["pathLength"]) and st.escaped == ost.escaped
+    assert st.nif_flops_per_sample == nif_assets.flops_per_sample(L32)
+    for c in "rgb":
+        np.testing.assert_allclose(rec[c], ref[c], rtol=NIF_RTOL_MAX, atol=1e-6)
+    mixed = [(k.astype(np.float16), b.astype(np.float16), relu) if i == 1 else (k, b, relu) for i, (k, b, relu) in enumerate(L32)]
+    L16 = [(k.astype(np.float16), b.astype(np.float16), relu) for k, b, relu in L32]
+    u = np.linspace(0.01, 0.99, 300, dtype=np.float32)
+    r.init_nif_weights(mixed, 12, META["max"], mean)
+    a = r.nif_infer(u, u[::-1].copy())
     r.init_nif_weights(L16, 12, META["max"], mean)
-    b = r.nif_infer(u, v)
+    b = r.nif_infer(u, u[::-1].copy())
     r.close()
     assert a.tobytes() == b.tobytes()
-    _check(oracle, ptmi_lib, L32, 12)
 
 
 def test_shapes_the_reference_would_reject(ptmi_lib):

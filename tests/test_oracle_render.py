@@ -151,3 +151,29 @@ def test_nif_against_numpy_and_golden(oracle):
     ref = np.exp(x[:, :3] * np.float32(nif_assets.URBAN_ALLEY_META["max"]) + np.float32(nif_assets.folded_mean()))
     np.testing.assert_allclose(out[:64], ref, rtol=5e-3)
     assert nif.flops_per_sample() == 1089283
+
+
+def test_nif_float32_mode_against_numpy(oracle):
+    """A model stored as float32 runs in float (NifModel.cpp:314: the matmul takes its kernel's type): the oracle's float mode
+    against an independent numpy restatement in float64 (no rounding to half between the layers, half-precision features), and
+    it is not the float16 model's answer."""
+    L = nif_assets.synthetic_nif(hidden=96, layer_count=4, embedding_dim=10, seed=4, dtype=np.float32)
+    meta = nif_assets.URBAN_ALLEY_META
+    nif = oracle.Nif(L, 10, meta["max"], nif_assets.folded_mean())
+    assert nif.float32 and nif.flops_per_sample() == nif_assets.flops_per_sample(L)
+    rng = np.random.default_rng(2)
+    u, v = rng.random(200, dtype=np.float32), rng.random(200, dtype=np.float32)
+    out = nif.infer(u, v)
+    f = np.stack([oracle.nif_encode(10, a, b) for a, b in zip(u, v)]).astype(np.float64)
+    x = f.copy()
+    for k, b, relu in L:
+        if x.shape[1] != k.shape[0]:
+            x = np.concatenate([x, f], 1)
+        x = x @ k.astype(np.float64) + b.astype(np.float64)
+        if relu:
+            x = np.maximum(x, 0.0)
+    ref = np.exp(x[:, :3] * meta["max"] + np.asarray(nif_assets.folded_mean(), dtype=np.float64))
+    np.testing.assert_allclose(out, ref, rtol=2e-5)
+    half = oracle.Nif([(k.astype(np.float16), b.astype(np.float16), r) for k, b, r in L], 10, meta["max"], nif_assets.folded_mean())
+    assert not half.float32
+    assert np.median(np.abs(half.infer(u, v) - out) / out) > 1e-4
