@@ -145,15 +145,17 @@ def test_unsupported_content_is_reported(host, tmp_path):
 
 
 @pytest.mark.gpu
-def test_cli_renders_from_converted_hdf5(host, oracle, tmp_path):
-    """--assets <dir> with nif_metadata.txt + converted.hdf5 (the reference's own asset layout), end to end."""
+@pytest.mark.parametrize("dtype,opts", [(np.float16, {}), (np.float32, dict(chunks=(64, 64), compression="gzip", shuffle=True))])
+def test_cli_renders_from_converted_hdf5(host, oracle, tmp_path, dtype, opts):
+    """--assets <dir> with nif_metadata.txt + converted.hdf5 (the reference's own asset layout), end to end: a float16 model
+    in contiguous datasets, and a float32 model (it then runs in float, NifModel.cpp:314) in gzip-compressed chunks."""
     exe = os.path.join(HOST, "ipu_trace")
     W, H, spp = 64, 48, 4
     assets = tmp_path / "assets.extra"
     assets.mkdir()
-    layers = nif_assets.synthetic_nif()
+    layers = nif_assets.synthetic_nif(dtype=dtype)
     nif_assets.write_metadata(str(assets / "nif_metadata.txt"))
-    write_keras_h5(str(assets / "converted.hdf5"), layers, vlen_config=True)
+    write_keras_h5(str(assets / "converted.hdf5"), layers, vlen_config=True, **opts)
     out = tmp_path / "img.png"
     r = subprocess.run([exe, "--assets", str(assets), "-w", str(W), "-h", str(H), "-s", str(spp), "--samples-per-step",
                         str(spp), "--max-path-length", "5", "-o", str(out)], capture_output=True, text=True, timeout=300)
