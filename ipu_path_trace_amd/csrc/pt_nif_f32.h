@@ -4,13 +4,25 @@
 // bias and applies ReLU in that type (:316-325), and casts the half-precision Fourier features to it (:211-216, :299-302).
 // Rounds 1-2 rounded float32 weights to binary16 on upload and ran the fp16 kernels; this path keeps them in float:
 // v_mfma_f32_32x32x2_f32 is an exact fp32 FMA chain in k order (cdna_hip_programming.md section 3, "FP32-input MFMA"), so a
-// layer's output is bit for bit the sequential fmaf sum the oracle forms.  It runs at the fp32 vector rate (1/16 of the fp16
+// layer's output is the sequential fmaf sum the oracle forms.  It runs at the fp32 matrix rate (157 TFLOP/s, 1/16 of the fp16
 // MFMA rate): a fidelity path for the models that need it, not a fast one -- the shipped NIFs are fp16
 // (nif_models/urban_alley_01_4k_fp16_yuv).
 //
-// Layer by layer over chunks of the queue, activations row-major [sample][feature] in two HBM buffers; one workgroup
-// computes 128 samples x 32 features (four waves of one 32 x 32 accumulator tile), operands staged through LDS in
-// k-chunks of 32.
+// Layer by layer over chunks of the queue, activations in two HBM buffers in the layout the MFMA hands them over in
+// ("packed", below); one wave computes 64 samples x 64 features, both operands loaded straight into the lane order the
+// instruction takes (no LDS, no barrier).
+//
+// Packed activations.  A layer is computed transposed, D^T = W^T x in^T: operand A = a 32-feature x 2-input tile of W^T
+// (lane (m, kk) holds W[k0 + kk][f0 + m]: two 128-byte rows of the row-major kernel per load), operand B = 2 inputs x 32
+// samples (lane (n, kk) holds in[sample n][k0 + kk]).  A lane of the result then owns, for ITS sample n, the features
+// 8 q + 4 kk + (0..3), q = 0..3, of a 32-feature tile: registers 4 q .. 4 q + 3 are four consecutive inputs of the next
+// layer.  They are stored as one float4 per lane,
+//     packed[((tile * (width / 8) + group) * 64 + lane) * 4 + c]  =  x[sample 32 tile + (lane & 31)][8 group + 4 (lane >> 5) + c],
+// so a wave's store and the next layer's load are each ONE contiguous kilobyte, and two v_permlane32_swap turn the loaded
+// (x, y, z, w) = ([k0|k4], [k1|k5], [k2|k6], [k3|k7]) (low | high half of the wave) into the B operands [k0|k1], [k2|k3],
+// [k4|k5], [k6|k7]: eight inputs per 16-byte load, consumed in k order.  (A row-major layout costs 4 x the L2 -> L1 bytes:
+// a lane's 16 bytes of a 128-byte line per load, the line gone from L1 before its next use -- measured 54 % MFMA busy
+// at full clock; this layout: see DESIGN.md 4.2c.)
 #pragma once
 #include "pt_nif_gemm.h"
 
@@ -20,17 +32,21 @@ struct NifF32Params {
   const float* w;            // this layer's kernel, row-major [k_act + k_in][ldw]
   const float* bias;         // [ldw] (zeros where the layer has none)
   uint32_t ldw;              // padded output width (multiple of 32)
-  uint32_t k_act, k_in;      // inputs taken from the previous activations / from the Fourier features
+  uint32_t k_act, k_in;      // inputs taken from the previous activations / from the Fourier features (multiples of 16)
   uint32_t relu;
-  const float* act_in;       // [chunk samples][lda]
-  const float* feat;         // [chunk samples][ldf]
-  float* act_out;            // [chunk samples][ldw]
+  const float* act_in;       // packed, width lda
+  const float* feat;         // packed, width ldf
+  float* act_out;            // packed, width ldw
   uint32_t lda, ldf;
   const uint32_t* total_tiles;
   uint32_t tile0, chunk_tiles;
 };
 
-// Fourier features of a chunk, row-major floats [sample][4 E]: [sin u, sin v, cos u, cos v] x E, the half-precision trig of
+__device__ __forceinline__ size_t nif32_packed(uint32_t tile, uint32_t width, uint32_t group, uint32_t lane) {
+  return (((size_t)tile * (width >> 3) + group) * 64u + lane) * 4u;
+}
+
+// Fourier features of a chunk, packed floats of width 4 E: [sin u, sin v, cos u, cos v] x E, the half-precision trig of
 // NifModel.cpp:200-216 cast to float (exact).  One wave per queue tile of 32 samples: lane = sample + 32 * coordinate.
 template <int E>
 __global__ __launch_bounds__(256) void nif32_encode_kernel(const NifParams P, const uint32_t* tile_start, uint32_t tile0,
@@ -46,63 +62,157 @@ __global__ __launch_bounds__(256) void nif32_encode_kernel(const NifParams P, co
     const TileRef r = find_tile(ts, P.n_regions, P, tile0 + lt);
     float coord = 0.5f;
     if (r.local + c < r.count) coord = h ? P.q_v[r.qbase + c] : P.q_u[r.qbase + c];
-    float* row = feat + ((size_t)lt * 32u + c) * (4 * E);
 #pragma unroll
     for (int g = 0; g < E / 4; ++g) {
       const half8 f = fourier_group(coord, g, P.n_freq);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        row[h * E + 4 * g + k] = (float)f[k];                 // sin u | sin v
-        row[2 * E + h * E + 4 * g + k] = (float)f[4 + k];     // cos u | cos v
-      }
+      const int fs = h * E + 4 * g, fc = 2 * E + fs;        // features fs..fs+3 = sin, fc..fc+3 = cos of this coordinate
+      *reinterpret_cast<float4*>(feat + nif32_packed(lt, 4 * E, fs >> 3, c + 32 * ((fs >> 2) & 1))) =
+          make_float4((float)f[0], (float)f[1], (float)f[2], (float)f[3]);
+      *reinterpret_cast<float4*>(feat + nif32_packed(lt, 4 * E, fc >> 3, c + 32 * ((fc >> 2) & 1))) =
+          make_float4((float)f[4], (float)f[5], (float)f[6], (float)f[7]);
     }
   }
 }
 
 // One dense layer in float over a chunk: out[s][f] = act(sum_k in[s][k] W[k][f] + b[f]), k over the previous activations and
 // then (first layer, concat layers) over the features -- the order of the reference's concat(x, input) (NifModel.cpp:305-308).
-__global__ __launch_bounds__(256) void nif32_layer_kernel(const NifF32Params P) {
-  __shared__ float As[128][33];     // [sample][k], padded: lanes of a half-wave read different rows
-  __shared__ float Bs[32][32];      // [k][feature]
-  const uint32_t ntiles = chunk_tile_count(P.total_tiles, P.tile0, P.chunk_tiles);
-  const uint32_t s0 = blockIdx.x * 128u;
-  if (s0 >= ntiles * 32u) return;
-  const uint32_t f0 = blockIdx.y * 32u;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int r = lane & 31, kk = lane >> 5;
-  f32x16 acc = (f32x16)(0.0f);
-  const uint32_t K = P.k_act + P.k_in;
-  for (uint32_t k0 = 0; k0 < K; k0 += 32u) {
-    // stage 128 x 32 inputs and 32 x 32 weights (k_act and k_in are multiples of 4; rows past K are zero-filled)
-    for (uint32_t i = threadIdx.x; i < 128u * 32u; i += 256u) {
-      const uint32_t row = i >> 5, k = k0 + (i & 31u);
-      float v = 0.f;
-      if (k < P.k_act) v = P.act_in[(size_t)(s0 + row) * P.lda + k];
-      else if (k < K) v = P.feat[(size_t)(s0 + row) * P.ldf + (k - P.k_act)];
-      As[row][i & 31u] = v;
-    }
-    for (uint32_t i = threadIdx.x; i < 32u * 32u; i += 256u) {
-      const uint32_t k = k0 + (i >> 5);
-      Bs[i >> 5][i & 31u] = (k < K) ? P.w[(size_t)k * P.ldw + f0 + (i & 31u)] : 0.f;
-    }
-    __syncthreads();
+//
+// A workgroup = four waves = 256 samples x 64 features; a wave = 64 samples x 64 features (2 x 2 accumulator tiles).  The
+// INPUTS go from memory straight into the B operand's lane order (one float4 per lane and tile, above).  The WEIGHTS are
+// the same for every sample block, and every wave of the chip walks them in step: loaded per wave they hit the same two or
+// three L2 channels at once (first version: 54 % MFMA busy at full clock).  So a workgroup brings each 16-input x 64-feature
+// slice in once, through LDS (4 KB, double-buffered, one barrier per slice = 32 MFMAs per wave), and the four waves read
+// their A operands from there (lanes read consecutive words: conflict-free).  A stage is 8 inputs = 16 MFMAs of 64 cycles;
+// the next stage's inputs and the next slice's weights are in flight while this one's MFMAs run.  The feature blocks of one
+// sample block are consecutive workgroups on ONE XCD (the block order below): they share the input tiles in that XCD's L2.
+struct NifF32Stage { float4 x[2]; };
+
+__device__ __forceinline__ void nif32_load_inputs(NifF32Stage& S, const float* in0, size_t tile_stride) {
+  S.x[0] = *reinterpret_cast<const float4*>(in0);
+  S.x[1] = *reinterpret_cast<const float4*>(in0 + tile_stride);
+}
+
+template <bool TWO>
+__device__ __forceinline__ void nif32_mfma_stage(const NifF32Stage& S, const float* ws, f32x16 (&acc)[2][2]) {
+  float x[2][4];
 #pragma unroll
-    for (int s = 0; s < 16; ++s)   // A = inputs (row = sample), B = weights (column = feature): D[sample][feature]
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[wave * 32 + r][2 * s + kk], Bs[2 * s + kk][r], acc, 0, 0, 0);
-    __syncthreads();
+  for (int t = 0; t < 2; ++t) {
+    const auto xy = __builtin_amdgcn_permlane32_swap(__float_as_uint(S.x[t].x), __float_as_uint(S.x[t].y), false, false);
+    const auto zw = __builtin_amdgcn_permlane32_swap(__float_as_uint(S.x[t].z), __float_as_uint(S.x[t].w), false, false);
+    x[t][0] = __uint_as_float(xy[0]); x[t][1] = __uint_as_float(zw[0]);
+    x[t][2] = __uint_as_float(xy[1]); x[t][3] = __uint_as_float(zw[1]);
   }
-  const float b = P.bias[f0 + r];
+  float w[4][2];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const uint32_t row = (uint32_t)((i & 3) + 8 * (i >> 2) + 4 * kk);
-    float o = acc[i] + b;                                           // addInPlace (:316-321)
-    if (P.relu) o = o > 0.f ? o : 0.f;                              // ReLU (:323-325)
-    P.act_out[(size_t)(s0 + wave * 32 + row) * P.ldw + f0 + r] = o;
+  for (int s = 0; s < 4; ++s) {   // ws = &slice[stage rows][kk][m]: row 2 s + kk, features m and 32 + m
+    w[s][0] = ws[2 * s * 64];
+    w[s][1] = TWO ? ws[2 * s * 64 + 32] : 0.f;
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {   // A = W^T (row = feature), B = inputs (column = sample): D[feature][sample]
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[s][0], x[0][s], acc[0][0], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[s][0], x[1][s], acc[1][0], 0, 0, 0);
+    if (TWO) {
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[s][1], x[0][s], acc[0][1], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[s][1], x[1][s], acc[1][1], 0, 0, 0);
+    }
   }
 }
 
+// Keeps the loads of a stage where they are written, a stage ahead of their use: the memory clobber stops the IR passes
+// from sinking them to the first use, the scheduling barrier stops the machine scheduler.
+#define NIF32_PIN() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+// Bias, activation and the packed store of a block's accumulators.
+template <bool TWO, bool RELU>
+__device__ __forceinline__ void nif32_store(const NifF32Params& P, const f32x16 (&acc)[2][2], uint32_t tl, uint32_t f0, uint32_t lane) {
+  float4 b[2][4];              // all bias loads first: a load issued between the stores would wait for every store before it
+#pragma unroll
+  for (int u = 0; u < (TWO ? 2 : 1); ++u)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)   // this lane's four features of register group q: f0 + 32 u + 8 q + 4 kk + (0..3)
+      b[u][q] = *reinterpret_cast<const float4*>(P.bias + f0 + 32u * u + 8u * q + 4u * (lane >> 5));
+  NIF32_PIN();
+#pragma unroll
+  for (int u = 0; u < (TWO ? 2 : 1); ++u) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t f = f0 + 32u * u + 8u * q + 4u * (lane >> 5);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        float4 o = make_float4(acc[t][u][4 * q] + b[u][q].x, acc[t][u][4 * q + 1] + b[u][q].y, acc[t][u][4 * q + 2] + b[u][q].z,
+                               acc[t][u][4 * q + 3] + b[u][q].w);      // addInPlace (:316-321)
+        if (RELU) { o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f; o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f; }   // (:323-325)
+        *reinterpret_cast<float4*>(P.act_out + nif32_packed(tl + t, P.ldw, f >> 3, lane)) = o;
+      }
+    }
+  }
+}
+
+template <bool TWO>   // TWO: both 32-feature tiles of the block exist (false: the last block of a 32 (mod 64) wide layer)
+__device__ __forceinline__ void nif32_block(const NifF32Params& P, float (*slice)[16][64], uint32_t tl, uint32_t f0) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t m = lane & 31u, kk = lane >> 5;
+  f32x16 acc[2][2];            // [sample tile][feature tile]
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) acc[t][u] = (f32x16)(0.0f);
+  const uint32_t K = P.k_act + P.k_in;                      // a multiple of 16 (pack_nif_f32)
+  auto inputs = [&](NifF32Stage& S, uint32_t k0) {
+    const bool act = k0 < P.k_act;
+    const float* base = act ? P.act_in : P.feat;
+    const uint32_t ld = act ? P.lda : P.ldf, kb = act ? k0 : k0 - P.k_act;
+    nif32_load_inputs(S, base + nif32_packed(tl, ld, kb >> 3, lane), (size_t)(ld >> 3) * 256u);
+  };
+  // the workgroup's weight slice of 16 inputs: thread i brings features 4 (i & 15) .. +3 of input row i >> 4
+  const uint32_t wr = threadIdx.x >> 4, wc = 4u * (threadIdx.x & 15u);
+  const bool wvalid = f0 + wc < P.ldw;                      // (ldw is a multiple of 32: a float4 is inside or outside)
+  const float* wsrc = P.w + (size_t)wr * P.ldw + (wvalid ? f0 + wc : 0u);
+  const float wkeep = wvalid ? 1.f : 0.f;                   // (a branch-free zero for the columns past the layer's width)
+  auto weights = [&](uint32_t k0) {
+    const float4 v = *reinterpret_cast<const float4*>(wsrc + (size_t)k0 * P.ldw);
+    return TWO ? v : make_float4(v.x * wkeep, v.y * wkeep, v.z * wkeep, v.w * wkeep);
+  };
+  NifF32Stage S0, S1;
+  inputs(S0, 0);
+  *reinterpret_cast<float4*>(&slice[0][wr][wc]) = weights(0);
+  __syncthreads();
+  for (uint32_t k0 = 0, it = 0; k0 < K; k0 += 16u, ++it) {
+    const float* ws = &slice[it & 1u][kk][m];
+    const float4 wn = weights(min(k0 + 16u, K - 16u));      // unconditional (the last one re-reads a slice): no branch, so the
+    inputs(S1, k0 + 8u);                                    // wait counts stay exact
+    NIF32_PIN();
+    nif32_mfma_stage<TWO>(S0, ws, acc);
+    NIF32_PIN();
+    inputs(S0, min(k0 + 16u, K - 8u));
+    NIF32_PIN();
+    nif32_mfma_stage<TWO>(S1, ws + 8 * 64, acc);
+    NIF32_PIN();
+    *reinterpret_cast<float4*>(&slice[(it + 1u) & 1u][wr][wc]) = wn;   // read last in iteration it - 1, before its barrier
+    __syncthreads();
+  }
+  if (P.relu) nif32_store<TWO, true>(P, acc, tl, f0, lane);
+  else nif32_store<TWO, false>(P, acc, tl, f0, lane);
+}
+
+__global__ __launch_bounds__(256, 2) void nif32_layer_kernel(const NifF32Params P) {
+  __shared__ float slice[2][16][64];
+  const uint32_t ntiles = chunk_tile_count(P.total_tiles, P.tile0, P.chunk_tiles);
+  // gridDim.x is a multiple of 8: workgroup b runs on XCD b % 8; give every XCD a contiguous run of output blocks
+  const uint32_t blk = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const uint32_t ncol = (P.ldw + 63u) / 64u;
+  const uint32_t sb = blk / ncol, col = blk - sb * ncol;   // sample block of 256 = 8 queue tiles (the chunk holds a multiple)
+  if (8u * sb >= ntiles) return;                            // the whole workgroup: no barrier is left waiting
+  const uint32_t tl = 8u * sb + 2u * (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t f0 = col * 64u;
+  if (f0 + 32u < P.ldw) nif32_block<true>(P, slice, tl, f0);
+  else nif32_block<false>(P, slice, tl, f0);
+}
+
 // Head (3 outputs) in float, decode (NifModel.cpp:221-245) and scatter (codelets.cpp:366-382).  One thread per sample, the
-// inputs in k order through fmaf: the sum the oracle forms.
+// inputs in k order through fmaf: the sum the oracle forms.  Lane c + 32 t of a wave is sample c of the wave's tile t; the
+// packed layout makes its loads 512-byte runs.
 struct NifF32Head {
   const float* w;            // [k_act + k_in][4]
   float bias0, bias1, bias2;
@@ -122,20 +232,23 @@ __global__ __launch_bounds__(256) void nif32_head_kernel(const NifParams P, cons
     const TileRef r = find_tile(ts, P.n_regions, P, Hd.tile0 + lt);
     if (r.local + c >= r.count) continue;
     const uint32_t qi = r.qbase + c;
-    const size_t sample = (size_t)lt * 32u + c;
     float acc[3] = {0.f, 0.f, 0.f};
-    const float* x = Hd.act_in + sample * Hd.lda;
-    for (uint32_t k = 0; k < Hd.k_act; ++k) {
-      const float xv = x[k];
-      const float4 wv = reinterpret_cast<const float4*>(Hd.w)[k];
-      acc[0] = fmaf(xv, wv.x, acc[0]); acc[1] = fmaf(xv, wv.y, acc[1]); acc[2] = fmaf(xv, wv.z, acc[2]);
-    }
-    const float* ft = Hd.feat + sample * Hd.ldf;
-    for (uint32_t k = 0; k < Hd.k_in; ++k) {
-      const float xv = ft[k];
-      const float4 wv = reinterpret_cast<const float4*>(Hd.w)[Hd.k_act + k];
-      acc[0] = fmaf(xv, wv.x, acc[0]); acc[1] = fmaf(xv, wv.y, acc[1]); acc[2] = fmaf(xv, wv.z, acc[2]);
-    }
+    const float4* wk = reinterpret_cast<const float4*>(Hd.w);
+    auto source = [&](const float* base, uint32_t ld, uint32_t kcount) {
+      for (uint32_t j = 0; j < (kcount >> 3); ++j) {
+        const float4 lo = *reinterpret_cast<const float4*>(base + nif32_packed(lt, ld, j, c));
+        const float4 hi = *reinterpret_cast<const float4*>(base + nif32_packed(lt, ld, j, c + 32u));
+        const float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float4 wv = wk[k];
+          acc[0] = fmaf(x[k], wv.x, acc[0]); acc[1] = fmaf(x[k], wv.y, acc[1]); acc[2] = fmaf(x[k], wv.z, acc[2]);
+        }
+        wk += 8;
+      }
+    };
+    source(Hd.act_in, Hd.lda, Hd.k_act);
+    source(Hd.feat, Hd.ldf, Hd.k_in);
     const float bias[3] = {Hd.bias0, Hd.bias1, Hd.bias2};
     const float mean[3] = {P.mean0, P.mean1, P.mean2};
     float bgr[3];

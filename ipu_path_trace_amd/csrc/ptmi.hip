@@ -1026,7 +1026,8 @@ int launch_nif_f32(pt_handle h, const ptd::NifParams& N) {
         G.act_in = in; G.feat = h->d_f32_feat; G.act_out = h->d_f32_act[l & 1u];
         G.lda = h->f32_lda; G.ldf = h->f32_ldf;
         G.total_tiles = h->d_tile_start + N.n_regions; G.tile0 = (uint32_t)tile0; G.chunk_tiles = chunk;
-        hipLaunchKernelGGL(ptd::nif32_layer_kernel, dim3(chunk / 4u, F.ldw / 32u), dim3(256), 0, h->stream, G);
+        const uint32_t blocks = chunk / 8u * ((F.ldw + 63u) / 64u);  // one 256-sample x 64-feature block per workgroup
+        hipLaunchKernelGGL(ptd::nif32_layer_kernel, dim3((blocks + 7u) / 8u * 8u), dim3(256), 0, h->stream, G);
       } else {
         ptd::NifF32Head Hd{};
         Hd.w = h->d_f32_weights + F.w_off;
@@ -1226,7 +1227,7 @@ static int upload_nif_f32(pt_handle h, const pt_layer* layers, uint32_t n_layers
   PT_HIP(hipSetDevice(h->cfg.device));
   PT_HIP(hipStreamSynchronize(h->stream));
   h->nif_valid = false;
-  const uint32_t chunk = 1024;   // queue tiles per chunk (32,768 samples): 2 x 42 MB of activations at width 320
+  const uint32_t chunk = 4096;   // queue tiles per chunk (131,072 samples; a multiple of 8: a workgroup takes eight): 2 x 168 MB of activations at width 320
   for (float** p : {&h->d_f32_weights, &h->d_f32_act[0], &h->d_f32_act[1], &h->d_f32_feat}) {
     if (*p) PT_HIP(hipFree(*p));
     *p = nullptr;

@@ -5,7 +5,8 @@ W,H=1104,1000
 spps = [int(x) for x in sys.argv[1:]] or [32, 300]
 DIAG = os.environ.get('QB_DIAG') == '1'   # the profiling build (libptmi_diag.so): the PTMI_* A/B switches only exist there
 r=ptmi.Renderer(W,H,max_path_length=8,diag=DIAG)
-L=A.synthetic_nif(hidden=int(os.environ.get('AB_HIDDEN','320')),layer_count=int(os.environ.get('AB_LAYERS','6')))
+L=A.synthetic_nif(hidden=int(os.environ.get('AB_HIDDEN','320')),layer_count=int(os.environ.get('AB_LAYERS','6')),
+                dtype=np.float32 if os.environ.get('AB_DTYPE') == 'f32' else np.float16)
 r.init_nif_weights(L,12,A.URBAN_ALLEY_META['max'],A.folded_mean())
 for spp in spps:
     r.init_render_settings(samples_per_step=spp)
