@@ -107,6 +107,24 @@ def test_float32_models_run_in_float(oracle, ptmi_lib, widths, emb, skips):
     assert np.median(np.abs(half - got) / np.abs(got)) > 1e-4     # the float path is not the fp16 path
 
 
+def test_float32_model_spans_chunks(oracle, ptmi_lib):
+    """More samples than one chunk of the float path holds (4096 queue tiles = 131,072): the second chunk reuses the packed
+    activation buffers, its last workgroup is partly filled, and a 32 (mod 64) wide layer takes the one-tile block."""
+    L32 = nif_assets.synthetic_nif(widths=[96, 64], embedding_dim=8, seed=12, dtype=np.float32)
+    mean = nif_assets.folded_mean()
+    onif = oracle.Nif(L32, 8, META["max"], mean)
+    rng = np.random.default_rng(4)
+    n = 131072 + 8 * 32 + 777
+    u = rng.random(n, dtype=np.float32)
+    v = rng.random(n, dtype=np.float32)
+    r = ptmi_lib.Renderer(64, 64)
+    r.init_nif_weights(L32, 8, META["max"], mean)
+    got, ref = r.nif_infer(u, v), onif.infer(u, v)
+    r.close()
+    rel = np.abs(got - ref) / np.abs(ref)
+    assert np.isfinite(got).all() and rel.max() < NIF_RTOL_MAX and np.median(rel) < 2e-5, (rel.max(), np.median(rel))
+
+
 def test_float32_model_renders_and_a_mixed_model_is_rounded(oracle, ptmi_lib):
     """The float path inside the whole step (queue, chunks, scatter, accumulate) against the oracle's float mode; and a
     float32 layer inside a float16 model is rounded to binary16 on upload (documented in include/ptmi.h): bit-identical
