@@ -145,6 +145,15 @@ struct pt_context {
   uint4* d_gemm_feat = nullptr;
   uint32_t* d_tile_start = nullptr;
   uint32_t gemm_chunk = 0;   // 32-sample tiles per chunk (multiple of 8); 0 = path not set up
+  // The layer-by-layer paths run the chunks of a queue round-robin on the NIF stream and on extra ones (chunk_stream):
+  // chunks are independent, so one chunk's layer launch fills the CUs another's is draining (the ramp / drain / gap of a
+  // launch is ~3-4 % of a 240 us layer).  Every chunk buffer therefore exists kChunkSets times (set s at offset s x *_set).
+  static constexpr int kChunkSets = 2;                  // chunks in flight (C5: 1 -> 2 streams +2.7 % on one box, 0 on another; 3: -1 %)
+  hipStream_t chunk_stream[kChunkSets - 1] = {};        // sets 1.. (set 0 runs on the NIF stream itself)
+  hipEvent_t chunk_fork = nullptr, chunk_join[kChunkSets - 1] = {};
+  int chunk_sets = kChunkSets;                           // profiling build: PTMI_CHUNK_STREAMS lowers it for the A/B
+  size_t gemm_act_set = 0, gemm_feat_set = 0, head_partial_set = 0;   // uint4 / uint4 / float4 elements per set
+  size_t f32_act_set = 0, f32_feat_set = 0;                            // floats per set
   unsigned long long* d_stamps = nullptr;   // profiling build: 256 phase stamps of the wide-NIF layer kernel
   int diag_fault_batch = -1;                // test build: batch whose NIF launch fails (pt_diag_inject_fault), -1 = none
 
@@ -841,16 +850,37 @@ int launch_nif_gemm32(pt_handle h, const ptd::NifParams& N) {
 
 #endif
 
+// Fork the chunk streams off the NIF stream / join them back (pt_context::chunk_stream).
+static int chunk_streams_fork(pt_handle h, int sets) {
+  if (sets < 2) return PT_OK;
+  PT_HIP(hipEventRecord(h->chunk_fork, h->stream));
+  for (int i = 0; i + 1 < sets; ++i) PT_HIP(hipStreamWaitEvent(h->chunk_stream[i], h->chunk_fork, 0));
+  return PT_OK;
+}
+static int chunk_streams_join(pt_handle h, int sets, int rc) {   // also after a failed launch: whatever was queued ends before the NIF stream goes on
+  for (int i = 0; i + 1 < sets; ++i) {
+    const hipError_t e1 = hipEventRecord(h->chunk_join[i], h->chunk_stream[i]), e2 = hipStreamWaitEvent(h->stream, h->chunk_join[i], 0);
+    if (rc == PT_OK && (e1 != hipSuccess || e2 != hipSuccess)) rc = fail(h, PT_ERR_HIP, "joining a chunk stream failed");
+  }
+  return rc;
+}
+static int chunk_sets_for(pt_handle h, uint64_t max_tiles, uint32_t chunk) {
+  int sets = (int)std::min<uint64_t>((max_tiles + chunk - 1) / chunk, (uint64_t)h->chunk_sets);
+#ifdef PTMI_DIAG_BUILD
+  if (const char* e = getenv("PTMI_CHUNK_STREAMS")) sets = std::max(1, std::min(sets, atoi(e)));   // A/B of the profiling build
+#endif
+  return std::max(sets, 1);
+}
+
 // Wide networks, one launch per layer over chunks of the queue (pt_nif_gemm.h).  The number of queue tiles is only
 // known on the device, so chunks are launched up to the queue's capacity and those past its end return at once.
 template <int E>
-void launch_nifg16_encode(pt_handle h, const ptd::NifParams& N, uint32_t tile0, uint32_t chunk) {
-  hipLaunchKernelGGL((ptd::nifg16_encode_kernel<E>), dim3((chunk + 3u) / 4u), dim3(256), 0, h->stream, N, h->d_tile_start, tile0, chunk,
-                     h->d_gemm_feat);
+void launch_nifg16_encode(pt_handle h, hipStream_t st, const ptd::NifParams& N, uint32_t tile0, uint32_t chunk, uint4* feat) {
+  hipLaunchKernelGGL((ptd::nifg16_encode_kernel<E>), dim3((chunk + 3u) / 4u), dim3(256), 0, st, N, h->d_tile_start, tile0, chunk, feat);
 }
 
 template <int FUSE>
-int launch_nifg16_layer(pt_handle h, const ptd::NifGemmParams& G, uint32_t grid) {
+int launch_nifg16_layer(pt_handle h, hipStream_t st, const ptd::NifGemmParams& G, uint32_t grid) {
   static std::atomic<unsigned long long> attr_set{0};
   if (int rc = set_dynamic_lds(h, reinterpret_cast<const void*>(&ptd::nifg16_layer_kernel<FUSE, 0>), ptd::kGemmLdsBytes, attr_set)) return rc;
 #ifdef PTMI_DIAG_BUILD
@@ -862,7 +892,7 @@ int launch_nifg16_layer(pt_handle h, const ptd::NifGemmParams& G, uint32_t grid)
                                hipFuncAttributeMaxDynamicSharedMemorySize, ptd::kGemmLdsBytes));                               \
     ptd::NifGemmParams GS = G;                                                                                                 \
     GS.stamps = h->d_stamps;                                                                                                   \
-    hipLaunchKernelGGL((ptd::nifg16_layer_kernel<FUSE, D>), dim3(grid), dim3(512), ptd::kGemmLdsBytes, h->stream, GS);          \
+    hipLaunchKernelGGL((ptd::nifg16_layer_kernel<FUSE, D>), dim3(grid), dim3(512), ptd::kGemmLdsBytes, st, GS);                 \
     PT_HIP(hipGetLastError());                                                                                                 \
     return PT_OK;                                                                                                              \
   }
@@ -870,7 +900,7 @@ int launch_nifg16_layer(pt_handle h, const ptd::NifGemmParams& G, uint32_t grid)
                    PT_LAYER16(16) PT_LAYER16(33) PT_LAYER16(40) PT_LAYER16(48) PT_LAYER16(160) PT_LAYER16(512) PT_LAYER16(544) PT_LAYER16(1024) PT_LAYER16(2048) PT_LAYER16(1056) PT_LAYER16(4096) PT_LAYER16(5120) default: break; }
 #undef PT_LAYER16
 #endif
-  hipLaunchKernelGGL((ptd::nifg16_layer_kernel<FUSE, 0>), dim3(grid), dim3(512), ptd::kGemmLdsBytes, h->stream, G);
+  hipLaunchKernelGGL((ptd::nifg16_layer_kernel<FUSE, 0>), dim3(grid), dim3(512), ptd::kGemmLdsBytes, st, G);
   PT_HIP(hipGetLastError());
   return PT_OK;
 }
@@ -888,7 +918,6 @@ int launch_nif_gemm(pt_handle h, const ptd::NifParams& N) {
   ptd::NifGemmParams G{};
   G.wpack = N.wpack;
   G.bpack = N.bpack;
-  G.feat = h->d_gemm_feat;
   G.act_stride = KS;
   G.feat_stride = IS;
   G.total_tiles = h->d_tile_start + N.n_regions;
@@ -898,7 +927,6 @@ int launch_nif_gemm(pt_handle h, const ptd::NifParams& N) {
   G.partial_stride = chunk * 32u;
   const uint32_t lh = n_layers - 1;
   ptd::NifHeadParams Hd{};
-  Hd.partial = h->d_head_partial;
   Hd.slices = 2u * FB;
   Hd.partial_stride = chunk * 32u;
   Hd.in_weights = ((N.concat_mask >> lh) & 1u) ? h->d_head_in : nullptr;
@@ -906,17 +934,27 @@ int launch_nif_gemm(pt_handle h, const ptd::NifParams& N) {
   Hd.bias0 = h->head_bias[0]; Hd.bias1 = h->head_bias[1]; Hd.bias2 = h->head_bias[2];
   Hd.relu = (N.relu_mask >> lh) & 1u;
   Hd.chunk_tiles = chunk;
-  for (uint64_t tile0 = 0; tile0 < max_tiles; tile0 += chunk) {
+  // chunks alternate between the NIF stream and chunk_stream (each with its own buffer set): see pt_context::chunk_stream
+  const int sets = chunk_sets_for(h, max_tiles, chunk);
+  if (int frc = chunk_streams_fork(h, sets)) return frc;
+  int rc = PT_OK;
+  uint32_t set = 0;
+  for (uint64_t tile0 = 0; tile0 < max_tiles && rc == PT_OK; tile0 += chunk, set = (set + 1u) % (uint32_t)sets) {
+    hipStream_t st = set ? h->chunk_stream[set - 1u] : h->stream;
+    uint4* const act[2] = {h->d_gemm_act[0] + set * h->gemm_act_set, h->d_gemm_act[1] + set * h->gemm_act_set};
+    uint4* const feat = h->d_gemm_feat + set * h->gemm_feat_set;
+    float4* const partial = h->d_head_partial + set * h->head_partial_set;
     G.tile0 = (uint32_t)tile0;
+    G.feat = feat;
     switch (h->nif_emb) {
-      case 4: launch_nifg16_encode<4>(h, N, G.tile0, chunk); break;
-      case 8: launch_nifg16_encode<8>(h, N, G.tile0, chunk); break;
-      case 12: launch_nifg16_encode<12>(h, N, G.tile0, chunk); break;
-      case 16: launch_nifg16_encode<16>(h, N, G.tile0, chunk); break;
-      default: return fail(h, PT_ERR_UNSUPPORTED_MODEL, "unsupported embedding dimension");
+      case 4: launch_nifg16_encode<4>(h, st, N, G.tile0, chunk, feat); break;
+      case 8: launch_nifg16_encode<8>(h, st, N, G.tile0, chunk, feat); break;
+      case 12: launch_nifg16_encode<12>(h, st, N, G.tile0, chunk, feat); break;
+      case 16: launch_nifg16_encode<16>(h, st, N, G.tile0, chunk, feat); break;
+      default: rc = fail(h, PT_ERR_UNSUPPORTED_MODEL, "unsupported embedding dimension"); continue;
     }
-    PT_HIP(hipGetLastError());
-    for (uint32_t l = 0; l + 1 < n_layers; ++l) {
+    if (hipGetLastError() != hipSuccess) { rc = fail(h, PT_ERR_HIP, "wide-NIF encode launch failed"); continue; }
+    for (uint32_t l = 0; l + 1 < n_layers && rc == PT_OK; ++l) {
       const bool concat = (N.concat_mask >> l) & 1u;
       const bool last = l + 2 == n_layers;   // the head rides in this layer's epilogue
       G.piece_base = N.piece_base[l];
@@ -924,16 +962,18 @@ int launch_nif_gemm(pt_handle h, const ptd::NifParams& N) {
       G.ks_act = l ? KS : 0u;
       G.ks_in = (l == 0 || concat) ? IS : 0u;
       G.relu = (N.relu_mask >> l) & 1u;
-      G.act_in = h->d_gemm_act[(l + 1u) & 1u];
-      G.act_out = last ? nullptr : h->d_gemm_act[l & 1u];
-      G.head_partial = last ? h->d_head_partial : nullptr;
-      if (int rc = last ? launch_nifg16_layer<1>(h, G, grid) : launch_nifg16_layer<0>(h, G, grid)) return rc;
+      G.act_in = act[(l + 1u) & 1u];
+      G.act_out = last ? nullptr : act[l & 1u];
+      G.head_partial = last ? partial : nullptr;
+      rc = last ? launch_nifg16_layer<1>(h, st, G, grid) : launch_nifg16_layer<0>(h, st, G, grid);
     }
+    if (rc) continue;
     Hd.tile0 = G.tile0;
-    hipLaunchKernelGGL(ptd::nifg16_finish_kernel, dim3((chunk + 7u) / 8u), dim3(256), 0, h->stream, N, Hd, h->d_tile_start);
-    PT_HIP(hipGetLastError());
+    Hd.partial = partial;
+    hipLaunchKernelGGL(ptd::nifg16_finish_kernel, dim3((chunk + 7u) / 8u), dim3(256), 0, st, N, Hd, h->d_tile_start);
+    if (hipGetLastError() != hipSuccess) rc = fail(h, PT_ERR_HIP, "wide-NIF finish launch failed");
   }
-  return PT_OK;
+  return chunk_streams_join(h, sets, rc);
 }
 
 // ---- float32 models (pt_nif_f32.h) -----------------------------------------------------------------------------
@@ -996,9 +1036,8 @@ int pack_nif_f32(pt_handle h, const std::vector<HostLayerF32>& L, uint32_t E, st
 }
 
 template <int E>
-void launch_nif32_encode(pt_handle h, const ptd::NifParams& N, uint32_t tile0, uint32_t chunk) {
-  hipLaunchKernelGGL((ptd::nif32_encode_kernel<E>), dim3((chunk + 3u) / 4u), dim3(256), 0, h->stream, N, h->d_tile_start, tile0, chunk,
-                     h->d_f32_feat);
+void launch_nif32_encode(pt_handle h, hipStream_t st, const ptd::NifParams& N, uint32_t tile0, uint32_t chunk, float* feat) {
+  hipLaunchKernelGGL((ptd::nif32_encode_kernel<E>), dim3((chunk + 3u) / 4u), dim3(256), 0, st, N, h->d_tile_start, tile0, chunk, feat);
 }
 
 int launch_nif_f32(pt_handle h, const ptd::NifParams& N) {
@@ -1007,40 +1046,48 @@ int launch_nif_f32(pt_handle h, const ptd::NifParams& N) {
   hipLaunchKernelGGL(ptd::nifg_scan_kernel, dim3(1), dim3(256), 0, h->stream, N.region_count, N.n_regions, h->d_tile_start);
   PT_HIP(hipGetLastError());
   const uint64_t max_tiles = (uint64_t)N.n_regions * ((N.region_cap + 31u) / 32u);
-  for (uint64_t tile0 = 0; tile0 < max_tiles; tile0 += chunk) {
+  // chunks alternate between the NIF stream and chunk_stream (each with its own buffer set): see pt_context::chunk_stream
+  const int sets = chunk_sets_for(h, max_tiles, chunk);
+  if (int frc = chunk_streams_fork(h, sets)) return frc;
+  int rc = PT_OK;
+  uint32_t set = 0;
+  for (uint64_t tile0 = 0; tile0 < max_tiles && rc == PT_OK; tile0 += chunk, set = (set + 1u) % (uint32_t)sets) {
+    hipStream_t st = set ? h->chunk_stream[set - 1u] : h->stream;
+    float* const act[2] = {h->d_f32_act[0] + set * h->f32_act_set, h->d_f32_act[1] + set * h->f32_act_set};
+    float* const feat = h->d_f32_feat + set * h->f32_feat_set;
     switch (h->nif_emb) {
-      case 4: launch_nif32_encode<4>(h, N, (uint32_t)tile0, chunk); break;
-      case 8: launch_nif32_encode<8>(h, N, (uint32_t)tile0, chunk); break;
-      case 12: launch_nif32_encode<12>(h, N, (uint32_t)tile0, chunk); break;
-      case 16: launch_nif32_encode<16>(h, N, (uint32_t)tile0, chunk); break;
-      default: return fail(h, PT_ERR_UNSUPPORTED_MODEL, "unsupported embedding dimension");
+      case 4: launch_nif32_encode<4>(h, st, N, (uint32_t)tile0, chunk, feat); break;
+      case 8: launch_nif32_encode<8>(h, st, N, (uint32_t)tile0, chunk, feat); break;
+      case 12: launch_nif32_encode<12>(h, st, N, (uint32_t)tile0, chunk, feat); break;
+      case 16: launch_nif32_encode<16>(h, st, N, (uint32_t)tile0, chunk, feat); break;
+      default: rc = fail(h, PT_ERR_UNSUPPORTED_MODEL, "unsupported embedding dimension"); continue;
     }
-    PT_HIP(hipGetLastError());
-    for (uint32_t l = 0; l < n_layers; ++l) {
+    if (hipGetLastError() != hipSuccess) { rc = fail(h, PT_ERR_HIP, "float32 NIF encode launch failed"); continue; }
+    for (uint32_t l = 0; l < n_layers && rc == PT_OK; ++l) {
       const pt_context::F32Layer& F = h->f32_layers[l];
-      const float* in = h->d_f32_act[(l + 1u) & 1u];
+      const float* in = act[(l + 1u) & 1u];
       if (l + 1 < n_layers) {
         ptd::NifF32Params G{};
         G.w = h->d_f32_weights + F.w_off; G.bias = h->d_f32_weights + F.b_off;
         G.ldw = F.ldw; G.k_act = F.k_act; G.k_in = F.k_in; G.relu = F.relu;
-        G.act_in = in; G.feat = h->d_f32_feat; G.act_out = h->d_f32_act[l & 1u];
+        G.act_in = in; G.feat = feat; G.act_out = act[l & 1u];
         G.lda = h->f32_lda; G.ldf = h->f32_ldf;
         G.total_tiles = h->d_tile_start + N.n_regions; G.tile0 = (uint32_t)tile0; G.chunk_tiles = chunk;
         const uint32_t blocks = chunk / 8u * ((F.ldw + 63u) / 64u);  // one 256-sample x 64-feature block per workgroup
-        hipLaunchKernelGGL(ptd::nif32_layer_kernel, dim3((blocks + 7u) / 8u * 8u), dim3(256), 0, h->stream, G);
+        hipLaunchKernelGGL(ptd::nif32_layer_kernel, dim3((blocks + 7u) / 8u * 8u), dim3(256), 0, st, G);
       } else {
         ptd::NifF32Head Hd{};
         Hd.w = h->d_f32_weights + F.w_off;
         Hd.k_act = F.k_act; Hd.k_in = F.k_in; Hd.relu = F.relu;
         Hd.bias0 = h->head_bias[0]; Hd.bias1 = h->head_bias[1]; Hd.bias2 = h->head_bias[2];
-        Hd.act_in = in; Hd.feat = h->d_f32_feat; Hd.lda = h->f32_lda; Hd.ldf = h->f32_ldf;
+        Hd.act_in = in; Hd.feat = feat; Hd.lda = h->f32_lda; Hd.ldf = h->f32_ldf;
         Hd.tile0 = (uint32_t)tile0; Hd.chunk_tiles = chunk;
-        hipLaunchKernelGGL(ptd::nif32_head_kernel, dim3((chunk + 7u) / 8u), dim3(256), 0, h->stream, N, Hd, h->d_tile_start);
+        hipLaunchKernelGGL(ptd::nif32_head_kernel, dim3((chunk + 7u) / 8u), dim3(256), 0, st, N, Hd, h->d_tile_start);
       }
-      PT_HIP(hipGetLastError());
+      if (hipGetLastError() != hipSuccess) rc = fail(h, PT_ERR_HIP, "float32 NIF layer launch failed");
     }
   }
-  return PT_OK;
+  return chunk_streams_join(h, sets, rc);
 }
 
 int launch_nif(pt_handle h, const ptd::NifParams& N, int blocks) {
@@ -1172,6 +1219,11 @@ int pt_create(const pt_config* cfg, pt_handle* out) {
     PT_HIPC(hipEventCreateWithFlags(&B.traced, hipEventDisableTiming));
     PT_HIPC(hipEventCreateWithFlags(&B.accumulated, hipEventDisableTiming));
   }
+  PT_HIPC(hipEventCreateWithFlags(&h->chunk_fork, hipEventDisableTiming));
+  for (int i = 0; i + 1 < pt_context::kChunkSets; ++i) {
+    PT_HIPC(hipStreamCreateWithPriority(&h->chunk_stream[i], hipStreamNonBlocking, prio_greatest));
+    PT_HIPC(hipEventCreateWithFlags(&h->chunk_join[i], hipEventDisableTiming));
+  }
   PT_HIPC(hipStreamCreateWithPriority(&h->trace_stream, hipStreamNonBlocking, prio_least));
   PT_HIPC(hipStreamCreateWithPriority(&h->acc_stream, hipStreamNonBlocking, prio_least));
 #ifdef PTMI_DIAG_BUILD
@@ -1203,6 +1255,11 @@ int pt_destroy(pt_handle h) {
   for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
   if (h->trace_stream && !h->serial) { (void)hipStreamSynchronize(h->trace_stream); (void)hipStreamDestroy(h->trace_stream); }
   if (h->acc_stream) { (void)hipStreamSynchronize(h->acc_stream); (void)hipStreamDestroy(h->acc_stream); }
+  for (int i = 0; i + 1 < pt_context::kChunkSets; ++i) {
+    if (h->chunk_stream[i]) { (void)hipStreamSynchronize(h->chunk_stream[i]); (void)hipStreamDestroy(h->chunk_stream[i]); }
+    if (h->chunk_join[i]) (void)hipEventDestroy(h->chunk_join[i]);
+  }
+  if (h->chunk_fork) (void)hipEventDestroy(h->chunk_fork);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return PT_OK;
@@ -1235,9 +1292,11 @@ static int upload_nif_f32(pt_handle h, const pt_layer* layers, uint32_t n_layers
   h->f32_chunk = 0;
   PT_HIP(dev_alloc(&h->d_f32_weights, blob.size()));
   PT_HIP(hipMemcpy(h->d_f32_weights, blob.data(), blob.size() * 4, hipMemcpyHostToDevice));
-  PT_HIP(dev_alloc(&h->d_f32_act[0], (size_t)chunk * 32 * Hp));
-  PT_HIP(dev_alloc(&h->d_f32_act[1], (size_t)chunk * 32 * Hp));
-  PT_HIP(dev_alloc(&h->d_f32_feat, (size_t)chunk * 32 * 4 * Ep));
+  h->f32_act_set = (size_t)chunk * 32 * Hp;                 // one buffer set per chunk in flight: pt_context::chunk_stream
+  h->f32_feat_set = (size_t)chunk * 32 * 4 * Ep;
+  PT_HIP(dev_alloc(&h->d_f32_act[0], pt_context::kChunkSets * h->f32_act_set));
+  PT_HIP(dev_alloc(&h->d_f32_act[1], pt_context::kChunkSets * h->f32_act_set));
+  PT_HIP(dev_alloc(&h->d_f32_feat, pt_context::kChunkSets * h->f32_feat_set));
   if (!h->d_tile_start) PT_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_tile_start), (ptd::kMaxRegions + 1) * 4));
   const HostLayerF32& head = L[n_layers - 1];
   for (int o = 0; o < 3; ++o) h->head_bias[o] = head.has_bias ? head.bias[o] : 0.f;
@@ -1359,16 +1418,19 @@ int pt_upload_nif(pt_handle h, const pt_layer* layers, uint32_t n_layers, uint32
       if (h->d_gemm_act[i]) PT_HIP(hipFree(h->d_gemm_act[i]));
       h->d_gemm_act[i] = nullptr;
       h->gemm_chunk = 0;
-      PT_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_gemm_act[i]), act_bytes));
+      PT_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_gemm_act[i]), pt_context::kChunkSets * act_bytes));   // one buffer set per chunk in flight: pt_context::chunk_stream
     }
+    h->gemm_act_set = act_bytes / 16;
     if (h->d_gemm_feat) PT_HIP(hipFree(h->d_gemm_feat));
     h->d_gemm_feat = nullptr;
-    PT_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_gemm_feat), feat_bytes));
+    PT_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_gemm_feat), pt_context::kChunkSets * feat_bytes));
+    h->gemm_feat_set = feat_bytes / 16;
     if (!h->d_tile_start) PT_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_tile_start), (ptd::kMaxRegions + 1) * 4));
     // fused head: partial sums of the 2 x (Hp / 256) slices, and the head's feature-input weights if it concatenates them
     if (h->d_head_partial) PT_HIP(hipFree(h->d_head_partial));
     h->d_head_partial = nullptr;
-    PT_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_head_partial), (size_t)2 * (plan.Hp / 256) * chunk * 32 * sizeof(float4)));
+    h->head_partial_set = (size_t)2 * (plan.Hp / 256) * chunk * 32;
+    PT_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_head_partial), pt_context::kChunkSets * h->head_partial_set * sizeof(float4)));
     if (h->d_head_in) PT_HIP(hipFree(h->d_head_in));
     h->d_head_in = nullptr;
     if (!head_in.empty()) {
@@ -1558,10 +1620,12 @@ int pt_path_trace(pt_handle h) {
   size_t e_begin_i = 0, e_end_i = 0;
   const int rc = enqueue_path_trace(h, spans, e_begin_i, e_end_i);
   // Drain all three streams whether or not the enqueue succeeded (a kernel fault surfaces here as well).
+  hipError_t s3 = hipSuccess;   // the chunk streams (forked from and joined to the NIF stream) first: a failed enqueue leaves nothing behind
+  for (hipStream_t cs : h->chunk_stream) { const hipError_t e = hipStreamSynchronize(cs); if (e != hipSuccess) s3 = e; }
   const hipError_t s0 = hipStreamSynchronize(h->stream), s1 = hipStreamSynchronize(h->trace_stream),
                    s2 = hipStreamSynchronize(h->acc_stream);
   if (rc) return rc;   // h->error names the failing call
-  for (hipError_t e : {s0, s1, s2})
+  for (hipError_t e : {s0, s1, s2, s3})
     if (e != hipSuccess) return fail(h, PT_ERR_HIP, std::string("path_trace: ") + hipGetErrorString(e));
   h->sample_cursor += h->samples_per_step;
 
