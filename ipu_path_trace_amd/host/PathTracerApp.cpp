@@ -1,5 +1,7 @@
 #include "PathTracerApp.hpp"
 
+#include <sstream>
+
 #include <atomic>
 #include <cmath>
 #include <cstdio>
@@ -80,6 +82,8 @@ std::vector<OptionSpec> PathTracerApp::addToolOptions() {
       {"synthetic-nif", 0, "false", false, true, "Use seeded stand-in NIF weights when <assets>/converted.ptnif is absent."},
       {"constant-env", 0, "", false, false, "r,g,b: constant-radiance environment instead of the NIF (BASELINE config C1)."},
       {"host-film", 0, "false", false, true, "Run the reference's step loop (worklist to the host every step, host film) even without load balancing."},
+      {"devices", 0, "", false, false, "GPU ordinal of every logical device, e.g. 0,1,2,3 (default: 0 .. ipus-1). Several logical devices may share a GPU (0,0): HDR tiles are then gathered through the host."},
+      {"host-gather", 0, "false", false, true, "Gather the HDR tiles of the devices through the host (one copy per device) instead of over an RCCL communicator."},
   };
 }
 
@@ -127,6 +131,31 @@ void PathTracerApp::attach() {
   const auto imageWidth = args.u32("width"), imageHeight = args.u32("height");
   const std::size_t numDevices = args.u32("ipus");
   geometry.numTiles *= numDevices;  // tiles scale with the device count as on a multi-IPU target
+  // logical device d runs on GPU deviceMap[d] (default d).  RCCL needs one GPU per rank: logical devices that share a GPU
+  // (a one-GPU box rehearsing the multi-device loop) gather their HDR tiles through the host instead.
+  std::vector<std::int32_t> deviceMap(numDevices);
+  for (std::size_t d = 0; d < numDevices; ++d) deviceMap[d] = (std::int32_t)d;
+  if (args.has("devices") && !args.str("devices").empty()) {
+    std::vector<std::int32_t> listed;
+    std::stringstream list(args.str("devices"));
+    for (std::string item; std::getline(list, item, ',');) {
+      std::size_t used = 0;
+      int v = -1;
+      try { v = std::stoi(item, &used); } catch (const std::exception&) { used = 0; }
+      if (used != item.size() || item.empty() || v < 0) throw std::runtime_error("--devices expects a comma-separated list of GPU ordinals, got '" + args.str("devices") + "'");
+      listed.push_back(v);
+    }
+    if (listed.size() != numDevices) throw std::runtime_error("--devices must name one GPU per logical device (--ipus " + std::to_string(numDevices) + ")");
+    deviceMap = listed;
+  }
+  hostGather = args.flag("host-gather");
+  for (std::size_t d = 0; d < numDevices && !hostGather; ++d)
+    for (std::size_t o = 0; o < d; ++o)
+      if (deviceMap[o] == deviceMap[d]) {
+        pt_log::info_("Logical devices {} and {} share GPU {}: HDR tiles are gathered through the host, not over RCCL", o, d, deviceMap[d]);
+        hostGather = true;
+        break;
+      }
   const auto raysPerJob = calculateMaxRaysPerTile(imageWidth, imageHeight, geometry);
   ipuJobs.reserve(geometry.numTiles);
   for (std::size_t t = 0; t < geometry.numTiles; ++t) ipuJobs.emplace_back(raysPerJob, args, t);   // PathTracerApp.cpp:323-326
@@ -141,7 +170,7 @@ void PathTracerApp::attach() {
     cfg.max_path_length = args.u32("max-path-length");
     cfg.aa_noise_type = aaNoiseType(args.str("aa-noise-type"));
     cfg.sample_precision = PT_SAMPLES_HALF;
-    cfg.device = (std::int32_t)d;
+    cfg.device = deviceMap[d];
     // with load balancing on the resident film the devices trade image tiles: room for any deal with equal tile counts
     deviceCapacity = itemsPerDevice;
     if (args.flag("enable-load-balancing"))
@@ -151,7 +180,9 @@ void PathTracerApp::attach() {
     if (pt_create(&cfg, &h)) throw std::runtime_error(std::string("Could not attach to device: ") + pt_last_error(nullptr));
     devices.push_back(h);
   }
-  if (numDevices > 1) {
+  if (numDevices > 1 && hostGather) {
+    pt_log::info_("HDR tiles of {} devices are gathered through the host", numDevices);
+  } else if (numDevices > 1) {
     // one RCCL communicator over the devices of this process: rank d = device d, HDR tiles are gathered to rank 0
     if (pt_comm_init_all(devices.data(), (int)numDevices))
       throw std::runtime_error(std::string("Could not create the RCCL communicator: ") + pt_last_error(devices[0]));
@@ -318,7 +349,9 @@ void PathTracerApp::executeResidentFilm(std::uint32_t steps) {
     if (step % saveInterval == 0 || step == steps) {
       hostProcessing.waitForCompletion();   // the previous save still reads filmRecords
       // the ONE exchange of the multi-GPU path: HDR tiles to device 0 over RCCL, then to the host film
+      // (--host-gather, or logical devices sharing a GPU: no communicator, every device hands its own tile to the host)
       onEveryDevice("HDR gather", [&](std::size_t d) {
+        if (hostGather) return pt_gather_hdr(devices[d], PT_HDR_FILM, slot, tiles.data() + d * slot * 3);
         return pt_gather_hdr(devices[d], PT_HDR_FILM, slot, d == 0 ? tiles.data() : nullptr);
       });
       filmRecords.clear();

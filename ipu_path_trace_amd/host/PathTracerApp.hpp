@@ -65,6 +65,7 @@ private:
   std::unique_ptr<PathTracerState> traceState;
   std::unique_ptr<PathTracerState> defunctTraceState;   // keeps defunct data alive while the async host task finishes on it
   std::size_t deviceCapacity = 0;   // work items per device incl. padding (pt_config.max_work_items)
+  bool hostGather = false;   ///< HDR tiles through the host (one copy per device) instead of the RCCL gather
   double finalSamplesPerSec = 0.0;
   std::chrono::steady_clock::time_point renderStartTime;   // reset when the UI restarts the render (PathTracerApp.cpp:669)
 };

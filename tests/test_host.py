@@ -681,6 +681,32 @@ def test_cli_on_the_reference_assets_directory(host, tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_multi_device_loop_on_one_gpu(host, tmp_path):
+    """The whole `--ipus N` step loop on a ONE-GPU box: N logical devices mapped onto GPU 0 (`--devices 0,0,0`), each with its
+    own handle, streams, worklist slice and thread (PathTracerApp::onEveryDevice), film resident per device, HDR tiles
+    gathered through the host (RCCL needs one GPU per rank: that exchange alone stays for a multi-GPU box -- DESIGN.md 6).
+    The film must equal the one-device film bit for bit (RNG keyed by pixel and sample index, per-pixel sums in step order),
+    also when the devices trade image tiles by measured path length at the save intervals (N3: pt_tile_costs, tile dealing,
+    pt_film_seed across devices), and in the reference's own loop (--host-film: read_results from every device)."""
+    one, _ = _run_cli(host, tmp_path, "one", ["--ipus", "1"], steps=5)
+    three, log = _run_cli(host, tmp_path, "three", ["--ipus", "3", "--devices", "0,0,0"], steps=5)
+    assert "share GPU 0" in log and "gathered through the host" in log and "film resident on the devices" in log
+    assert three.tobytes() == one.tobytes()
+    two_lb, log = _run_cli(host, tmp_path, "two_lb", ["--ipus", "2", "--devices", "0,0", "--enable-load-balancing", "--log-level", "debug"], steps=5)
+    assert log.count("Load balancing finished") == 2 and "image tiles over 2 devices" in log
+    assert two_lb.tobytes() == one.tobytes()
+    two_host, log = _run_cli(host, tmp_path, "two_host", ["--ipus", "2", "--devices", "0,0", "--host-film"], steps=5)
+    assert "the reference's" in log
+    assert two_host.tobytes() == one.tobytes()
+    # a list that does not match --ipus, or is not a list of ordinals, is refused before anything is attached
+    exe = os.path.join(HOST, "ipu_trace")
+    for bad in ("0", "0,x", "0,-1"):
+        r = subprocess.run([exe, "--assets", str(tmp_path / "assets.extra"), "-w", "32", "-h", "32", "-s", "2", "--samples-per-step", "2",
+                            "-o", str(tmp_path / "bad.png"), "--ipus", "2", "--devices", bad], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 1 and "--devices" in r.stdout, r.stdout[-500:]
+
+
+@pytest.mark.gpu
 def test_cli_two_devices_or_a_clean_refusal(host, tmp_path):
     """`--ipus 2`: on a box with two or more GPUs the film must equal the one-GPU film bit for bit (worklist slices per
     device, RNG keyed by pixel and sample index, resident film gathered by pt_gather_hdr over an RCCL communicator of two
