@@ -273,4 +273,6 @@ __global__ __launch_bounds__(256) void nif32_head_kernel(const NifParams P, cons
   }
 }
 
+#undef NIF32_PIN
+
 }  // namespace ptd

@@ -262,6 +262,12 @@ def test_cli_contract_without_gpu(host, tmp_path):
         r = subprocess.run([exe, "-o", "x.png", "--assets", str(tmp_path), "--constant-env", "1,1,1", opt, "0"],
                            capture_output=True, text=True)
         assert r.returncode == 1 and msg in r.stdout, (opt, r.returncode, r.stdout[-500:])
+    # --devices (this build's addition) must name one GPU ordinal per logical device; refused before any device is touched
+    for bad in ("0", "0,x", "0,-1", "0,,1"):
+        r = subprocess.run([exe, "-o", "x.png", "--assets", str(tmp_path), "--constant-env", "1,1,1", "--ipus", "2", "--devices", bad],
+                           capture_output=True, text=True)
+        assert r.returncode == 1 and "--devices" in r.stdout, (bad, r.returncode, r.stdout[-500:])
+    assert "--devices" in help_text and "--host-gather" in help_text
 
 
 @pytest.mark.gpu
