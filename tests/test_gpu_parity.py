@@ -78,6 +78,37 @@ def test_render_constant_sky_bit_exact_config_c1(oracle, ptmi_lib):
     r.close()
 
 
+@pytest.mark.parametrize("opts", [
+    dict(max_path_length=1),                                                    # every path ends at its first hit or escapes
+    dict(max_path_length=3, roulette_depth=1, stop_prob=0.6),                   # roulette from the first bounce on, most paths stop
+    dict(max_path_length=12, roulette_depth=20, stop_prob=0.3),                 # roulette never starts: paths run to the depth limit
+    dict(max_path_length=8, refractive_index=1.33, stop_prob=0.0),              # water instead of glass, roulette that never stops
+    dict(max_path_length=6, aa_noise_type=1, aa_noise_scale=1.5, fov_degrees=40.0, env_rotation_degrees=123.0, seed=987654321987),
+])
+def test_render_bit_exact_under_non_default_options(oracle, ptmi_lib, opts):
+    """The CLI options that shape the sampling loop (PathTracerApp.cpp:797-817: --max-path-length, --roulette-depth,
+    --stop-prob, --refractive-index, --aa-noise-type/-scale, --fov, --env-map-rotation, --seed) away from their defaults:
+    the three-phase trace kernel (camera rays / first shading / persistent loop) against the oracle, every TraceRecord
+    field identical, on an image whose width is not a multiple of the wave size and over a ragged last batch."""
+    O = oracle
+    W, H, spp = 203, 77, 7
+    create = {k: opts[k] for k in ("max_path_length", "roulette_depth", "stop_prob", "refractive_index", "aa_noise_type") if k in opts}
+    settings = {k: opts[k] for k in ("seed", "aa_noise_scale", "fov_degrees", "env_rotation_degrees") if k in opts}
+    cfg = O.make_config(width=W, height=H, env_rgb=(0.7, 1.1, 0.4), **opts)
+    ref = O.worklist(W, H)
+    st = O.render(cfg, None, ref, 0, spp)
+    r = ptmi_lib.Renderer(W, H, iterations_per_batch=3, **create)
+    r.set_constant_env((0.7, 1.1, 0.4))
+    r.init_render_settings(samples_per_step=spp, **settings)
+    got = ptmi_lib.worklist(W, H)
+    r.setup(got)
+    r.path_trace()
+    gst = r.read_results(got)
+    r.close()
+    assert (gst.paths, gst.segments, gst.escaped) == (st.paths, st.segments, st.escaped)
+    assert got.tobytes() == ref.tobytes()
+
+
 def test_render_backward_fold_matches_forward(oracle, ptmi_lib):
     """GPU (forward throughput) against the reference's backward fold (codelets.cpp:255-292): rounding only."""
     O = oracle
