@@ -49,7 +49,7 @@ std::vector<OptionSpec> PathTracerApp::addToolOptions() {
       {"ipus", 0, "1", false, false, "Number of devices to use (MI355X GPUs here)."},
       {"save-exe", 0, "", false, false, "IPU-only (graph cache): accepted and ignored."},
       {"load-exe", 0, "", false, false, "IPU-only (graph cache): accepted and ignored."},
-      {"compile-only", 0, "false", false, true, "IPU-only: accepted and ignored."},
+      {"compile-only", 0, "false", false, true, "Validate the options and the NIF assets, then stop without touching a device (the reference compiles its graph and stops)."},
       {"defer-attach", 0, "false", false, true, "IPU-only: accepted and ignored."},
       {"log-level", 0, "info", false, false, "One of 'trace', 'debug', 'info', 'warn', 'err', 'critical', 'off'."},
       // PathTracerApp.cpp:794-830

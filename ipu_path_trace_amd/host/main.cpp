@@ -53,6 +53,13 @@ int main(int argc, char** argv) {
     auto opts = parseOptions(argc, argv, specs);
     pt_log::setLevel(opts.str("log-level"));
     app.init(opts);
+    if (opts.flag("compile-only")) {
+      // The reference builds and compiles its graph (validating options and the NIF on the way), optionally saves the
+      // executable and stops without attaching to a device (ipu_utils.hpp:523-526, PathTracerApp.cpp:91-92).  There is no
+      // graph to compile here: options and assets have been validated by init(); nothing is rendered.
+      pt_log::info_("Compile only mode selected: finished.");
+      return EXIT_SUCCESS;
+    }
     app.attach();
     app.execute();
     return EXIT_SUCCESS;

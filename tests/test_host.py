@@ -268,6 +268,14 @@ def test_cli_contract_without_gpu(host, tmp_path):
                            capture_output=True, text=True)
         assert r.returncode == 1 and "--devices" in r.stdout, (bad, r.returncode, r.stdout[-500:])
     assert "--devices" in help_text and "--host-gather" in help_text
+    # --compile-only: the reference compiles its graph and stops before attaching (ipu_utils.hpp:523-526); here the options and
+    # the assets are validated and nothing is rendered -- it works without a GPU and writes no image
+    r = subprocess.run([exe, "-o", str(tmp_path / "never.png"), "--assets", str(tmp_path), "--constant-env", "1,1,1", "--compile-only",
+                        "--save-exe", "graph"], capture_output=True, text=True)
+    assert r.returncode == 0 and "Compile only mode selected: finished." in r.stdout, r.stdout[-500:]
+    assert not (tmp_path / "never.png").exists()
+    r = subprocess.run([exe, "-o", str(tmp_path / "never.png"), "--assets", str(tmp_path), "--compile-only"], capture_output=True, text=True)
+    assert r.returncode != 0 and "Could not load NIF model" in r.stdout      # a bad asset directory still fails the "compile"
 
 
 @pytest.mark.gpu
