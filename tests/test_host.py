@@ -274,6 +274,9 @@ def test_cli_contract_without_gpu(host, tmp_path):
                         "--save-exe", "graph"], capture_output=True, text=True)
     assert r.returncode == 0 and "Compile only mode selected: finished." in r.stdout, r.stdout[-500:]
     assert not (tmp_path / "never.png").exists()
+    r = subprocess.run([exe, "-o", str(tmp_path / "x.jpg"), "--assets", str(tmp_path), "--constant-env", "1,1,1", "--compile-only"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and "does not end in .png" in r.stdout      # cv::imwrite would pick JPEG; only PNG is built in: say so
     r = subprocess.run([exe, "-o", str(tmp_path / "never.png"), "--assets", str(tmp_path), "--compile-only"], capture_output=True, text=True)
     assert r.returncode != 0 and "Could not load NIF model" in r.stdout      # a bad asset directory still fails the "compile"
 
