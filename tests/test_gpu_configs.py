@@ -1,5 +1,7 @@
 """BASELINE.json configurations at full size on the GPU, checked through size-independent properties and through
 the oracle on a random subset of pixels (the oracle cannot render the full sizes in test time)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -175,6 +177,42 @@ def test_config_c5_wide_nif_8x1024(oracle, ptmi_lib):
     for c in "rgb":
         np.testing.assert_allclose(rec[c], ref[c], rtol=NIF_RTOL, atol=1e-6)
     r.close()
+
+
+@pytest.mark.parametrize("dtype,hidden,nlayers", [(np.float16, 512, 3), (np.float32, 128, 3)])
+def test_chunks_in_flight_on_two_streams_change_nothing(ptmi_lib, dtype, hidden, nlayers):
+    """The layer-by-layer NIF paths (wide fp16: pt_nif_gemm.h; float32: pt_nif_f32.h) run the chunks of a queue alternately on
+    two streams with a buffer set each.  A race between the two (a shared buffer, a missing join before the accumulate)
+    would show as a film that differs from the one-stream film or from run to run: three renders of a queue of five chunks
+    -- two streams, two streams again in a fresh handle, one stream (profiling build, PTMI_CHUNK_STREAMS=1) -- must be
+    bit-identical in every TraceRecord field."""
+    W, H, spp = 448, 400, 4                       # 716,800 paths in one batch: ~5 chunks of 131,072 escaped samples
+    layers = nif_assets.synthetic_nif(hidden=hidden, layer_count=nlayers, seed=17, dtype=dtype)
+    mean = nif_assets.folded_mean()
+
+    def film(diag, streams):
+        if streams:
+            os.environ["PTMI_CHUNK_STREAMS"] = streams
+        try:
+            r = ptmi_lib.Renderer(W, H, max_path_length=6, iterations_per_batch=spp, diag=diag)
+            r.init_nif_weights(layers, 12, nif_assets.URBAN_ALLEY_META["max"], mean)
+            r.init_render_settings(samples_per_step=spp)
+            work = ptmi_lib.worklist(W, H)
+            r.setup(work)
+            r.path_trace()
+            r.path_trace()                         # a second step over the same buffers
+            st = r.read_results(work)
+            r.close()
+        finally:
+            os.environ.pop("PTMI_CHUNK_STREAMS", None)
+        assert st.escaped > 4 * 131072 // 2        # per step of 4 iterations in one batch: more than two chunks' worth
+        return work
+
+    a, b = film(False, None), film(False, None)
+    one = film(True, "1")
+    assert a.tobytes() == b.tobytes()
+    assert a.tobytes() == one.tobytes()
+    assert np.all(np.isfinite(a["r"])) and a["r"].max() > 0
 
 
 def test_redeal_by_measured_path_length_keeps_the_film(ptmi_lib):
