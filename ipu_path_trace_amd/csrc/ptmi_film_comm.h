@@ -1,0 +1,368 @@
+// ptmi_film_comm.h -- resident film, per-tile costs and the RCCL hand-off of HDR tiles (entry points of include/ptmi.h)
+// Part of the one translation unit ptmi.hip (host side of include/ptmi.h); included there, in this order:
+// ptmi_context.h, ptmi_nif_pack.h, ptmi_nif_launch.h, [the entry points in ptmi.hip], ptmi_film_comm.h.
+#pragma once
+
+extern "C" {
+
+// ---- multi-GPU film hand-off over RCCL --------------------------------------------------------------------------
+// The path shards over pixels with no exchange of ray data (reference: one NIF replica per IPU, "no inter-ipu exchange",
+// PathTracerApp.cpp:205-252; results only meet on the host film, AccumulatedImage.cpp:59-74).  The one exchange step is
+// this gather of HDR tiles to rank 0 at a save interval: every peer sends its tile straight to the root over its own
+// xGMI link (grouped ncclSend / ncclRecv -- never a ring), 12 B per work item.
+//
+// No call in here can block for ever.  Communicators are NON-BLOCKING (ncclConfig_t::blocking = 0): every RCCL call
+// returns at once, and its completion -- connection set-up with a peer included -- is polled with
+// ncclCommGetAsyncError against the handle's deadline (pt_comm_set_timeout, default 120 s); the device side is polled
+// with hipStreamQuery against the same deadline.  On expiry, on an asynchronous RCCL error, or when another thread asks
+// (pt_comm_abort) the communicator is aborted (ncclCommAbort ends the kernels still waiting for a peer), the stream is
+// drained, and the call returns PT_ERR_COMM; the handle then refuses further gathers until it is given a new communicator.
+// Every step that can fail locally (argument checks, allocations, the export kernel) runs BEFORE a rank enters the
+// exchange, so a rank that returns early never leaves its peers inside a collective it has half joined: they time out.
+
+#define PT_NCCL(call)                                                                        \
+  do {                                                                                       \
+    ncclResult_t r_ = (call);                                                                \
+    if (r_ != ncclSuccess && r_ != ncclInProgress) {                                         \
+      h->error = std::string(#call) + ": " + ncclGetErrorString(r_);                         \
+      return PT_ERR_COMM;                                                                    \
+    }                                                                                        \
+  } while (0)
+
+using comm_clock = std::chrono::steady_clock;
+
+static void comm_backoff(unsigned& spins) {
+  if (++spins < 200) std::this_thread::yield();
+  else std::this_thread::sleep_for(std::chrono::microseconds(spins < 2000 ? 50 : 500));
+}
+
+// Abort the handle's communicator and leave the handle without one.  Kernels of this communicator still spinning on a
+// peer see the abort flag and exit, so the stream can be drained afterwards.
+static void comm_abort_now(pt_handle h) {
+  if (h->comm) (void)ncclCommAbort(h->comm);
+  h->comm = nullptr;
+  h->comm_broken = true;
+  h->comm_slot_agreed = 0;
+  h->comm_abort_req.store(false);
+}
+
+static int comm_fail(pt_handle h, const std::string& why) {
+  comm_abort_now(h);
+  (void)hipStreamSynchronize(h->stream);   // nothing of the aborted exchange is left running on the caller's buffers
+  h->error = why + " -- communicator aborted";
+  return PT_ERR_COMM;
+}
+
+// Host side of a non-blocking RCCL call: wait until the communicator has left ncclInProgress.
+static int comm_wait_host(pt_handle h, const char* what, comm_clock::time_point deadline) {
+  unsigned spins = 0;
+  for (;;) {
+    ncclResult_t st = ncclSuccess;
+    const ncclResult_t q = ncclCommGetAsyncError(h->comm, &st);
+    if (q != ncclSuccess) return comm_fail(h, std::string(what) + ": ncclCommGetAsyncError: " + ncclGetErrorString(q));
+    if (st == ncclSuccess) return PT_OK;
+    if (st != ncclInProgress) return comm_fail(h, std::string(what) + ": " + ncclGetErrorString(st));
+    if (h->comm_abort_req.load()) return comm_fail(h, std::string(what) + ": aborted by pt_comm_abort");
+    if (comm_clock::now() > deadline)
+      return comm_fail(h, std::string(what) + ": no progress within " + std::to_string(h->comm_timeout_ms) + " ms (a peer is missing or has failed)");
+    comm_backoff(spins);
+  }
+}
+
+// Device side: wait until everything queued on the handle's stream has finished.
+static int comm_wait_stream(pt_handle h, const char* what, comm_clock::time_point deadline) {
+  unsigned spins = 0;
+  for (;;) {
+    const hipError_t e = hipStreamQuery(h->stream);
+    (void)hipGetLastError();   // hipErrorNotReady must not surface from a later hipGetLastError()
+    if (e == hipSuccess) return PT_OK;
+    if (e != hipErrorNotReady) {
+      const std::string msg = std::string(what) + ": " + hipGetErrorString(e);
+      comm_abort_now(h);
+      h->error = msg;
+      return PT_ERR_HIP;
+    }
+    if (h->comm) {
+      ncclResult_t st = ncclSuccess;
+      if (ncclCommGetAsyncError(h->comm, &st) == ncclSuccess && st != ncclSuccess && st != ncclInProgress)
+        return comm_fail(h, std::string(what) + ": " + ncclGetErrorString(st));
+      if (h->comm_abort_req.load()) return comm_fail(h, std::string(what) + ": aborted by pt_comm_abort");
+      if (comm_clock::now() > deadline)
+        return comm_fail(h, std::string(what) + ": the exchange did not finish within " + std::to_string(h->comm_timeout_ms) + " ms (a peer is missing or has failed)");
+    }
+    comm_backoff(spins);
+  }
+}
+
+static comm_clock::time_point comm_deadline(pt_handle h) {
+  return comm_clock::now() + std::chrono::milliseconds(h->comm_timeout_ms);
+}
+
+int pt_comm_get_unique_id(void* id_out) {
+  static_assert(sizeof(ncclUniqueId) == PT_COMM_ID_BYTES, "PT_COMM_ID_BYTES must match ncclUniqueId");
+  if (!id_out) { g_create_error = "null id buffer"; return PT_ERR_INVALID_ARGUMENT; }
+  ncclUniqueId id;
+  ncclResult_t r = ncclGetUniqueId(&id);
+  if (r != ncclSuccess) { g_create_error = std::string("ncclGetUniqueId: ") + ncclGetErrorString(r); return PT_ERR_COMM; }
+  memcpy(id_out, &id, sizeof(id));
+  return PT_OK;
+}
+
+int pt_comm_set_timeout(pt_handle h, uint32_t milliseconds) {
+  if (!h) return PT_ERR_INVALID_ARGUMENT;
+  if (milliseconds == 0) return fail(h, PT_ERR_INVALID_ARGUMENT, "the communicator deadline must be > 0 ms");
+  h->comm_timeout_ms = milliseconds;
+  return PT_OK;
+}
+
+int pt_comm_abort(pt_handle h) {
+  if (!h) return PT_ERR_INVALID_ARGUMENT;
+  h->comm_abort_req.store(true);   // the only field another thread may touch; the owning thread's polling loop acts on it
+  return PT_OK;
+}
+
+static int comm_local_buffers(pt_handle h) {
+  if (!h->d_slot_check) PT_HIP(dev_alloc(&h->d_slot_check, 2));
+  return PT_OK;
+}
+
+int pt_comm_init_rank(pt_handle h, const void* id_in, int rank, int world) {
+  if (!h) return PT_ERR_INVALID_ARGUMENT;
+  if (!id_in || world < 1 || rank < 0 || rank >= world) return fail(h, PT_ERR_INVALID_ARGUMENT, "bad communicator arguments");
+  if (h->comm) return fail(h, PT_ERR_INVALID_ARGUMENT, "the handle already has a communicator");
+  PT_HIP(hipSetDevice(h->cfg.device));
+  if (int rc = comm_local_buffers(h)) return rc;
+  ncclUniqueId id;
+  memcpy(&id, id_in, sizeof(id));
+  ncclConfig_t cfg = NCCL_CONFIG_INITIALIZER;
+  cfg.blocking = 0;
+  h->comm_broken = false;
+  h->comm_abort_req.store(false);
+  h->comm_slot_agreed = 0;
+  const auto deadline = comm_deadline(h);
+  ncclComm_t comm = nullptr;
+  const ncclResult_t r = ncclCommInitRankConfig(&comm, world, id, rank, &cfg);
+  if (r != ncclSuccess && r != ncclInProgress) {
+    if (comm) (void)ncclCommAbort(comm);
+    return fail(h, PT_ERR_COMM, std::string("ncclCommInitRankConfig: ") + ncclGetErrorString(r));
+  }
+  h->comm = comm;
+  if (int rc = comm_wait_host(h, "communicator set-up", deadline)) return rc;   // a rank that never arrives ends here, not in a hang
+  h->comm_rank = rank;
+  h->comm_world = world;
+  return PT_OK;
+}
+
+int pt_comm_init_all(pt_handle* handles, int n) {
+  if (!handles || n < 1) { g_create_error = "bad communicator arguments"; return PT_ERR_INVALID_ARGUMENT; }
+  pt_handle h = handles[0];
+  if (!h) { g_create_error = "null handle"; return PT_ERR_INVALID_ARGUMENT; }
+  std::vector<int> devs(n);
+  for (int i = 0; i < n; ++i) {
+    if (!handles[i]) return fail(h, PT_ERR_INVALID_ARGUMENT, "null handle in the list");
+    if (handles[i]->comm) return fail(h, PT_ERR_INVALID_ARGUMENT, "a handle already has a communicator");
+    devs[i] = handles[i]->cfg.device;
+    for (int j = 0; j < i; ++j)
+      if (devs[j] == devs[i]) return fail(h, PT_ERR_INVALID_ARGUMENT, "RCCL needs one device per rank: two handles share device " + std::to_string(devs[i]));
+  }
+  for (int i = 0; i < n; ++i) {   // local, fallible steps first
+    if (hipSetDevice(devs[i]) != hipSuccess) return fail(h, PT_ERR_HIP, "hipSetDevice failed for device " + std::to_string(devs[i]));
+    if (int rc = comm_local_buffers(handles[i])) { h->error = handles[i]->error; return rc; }
+  }
+  ncclUniqueId id;
+  PT_NCCL(ncclGetUniqueId(&id));
+  ncclConfig_t cfg = NCCL_CONFIG_INITIALIZER;
+  cfg.blocking = 0;
+  std::vector<ncclComm_t> comms(n, nullptr);
+  auto abort_all = [&]() { for (auto c : comms) if (c) (void)ncclCommAbort(c); };
+  // one process, several devices: the rank-wise initialisations form one group
+  PT_NCCL(ncclGroupStart());
+  for (int i = 0; i < n; ++i) {
+    ncclResult_t r = (hipSetDevice(devs[i]) == hipSuccess) ? ncclCommInitRankConfig(&comms[i], n, id, i, &cfg) : ncclUnhandledCudaError;
+    if (r != ncclSuccess && r != ncclInProgress) {
+      (void)ncclGroupEnd();
+      abort_all();
+      return fail(h, PT_ERR_COMM, std::string("ncclCommInitRankConfig: ") + ncclGetErrorString(r));
+    }
+  }
+  {
+    const ncclResult_t r = ncclGroupEnd();
+    if (r != ncclSuccess && r != ncclInProgress) { abort_all(); return fail(h, PT_ERR_COMM, std::string("ncclGroupEnd: ") + ncclGetErrorString(r)); }
+  }
+  const auto deadline = comm_deadline(h);
+  unsigned spins = 0;
+  for (int i = 0; i < n;) {
+    ncclResult_t st = ncclSuccess;
+    const ncclResult_t q = comms[i] ? ncclCommGetAsyncError(comms[i], &st) : ncclInternalError;
+    if (q == ncclSuccess && st == ncclSuccess) { ++i; continue; }
+    if (q != ncclSuccess || st != ncclInProgress || comm_clock::now() > deadline) {
+      abort_all();
+      return fail(h, PT_ERR_COMM, "communicator set-up of rank " + std::to_string(i) + " failed or timed out: " +
+                                      ncclGetErrorString(q != ncclSuccess ? q : st));
+    }
+    comm_backoff(spins);
+  }
+  for (int i = 0; i < n; ++i) {
+    handles[i]->comm = comms[i];
+    handles[i]->comm_rank = i;
+    handles[i]->comm_world = n;
+    handles[i]->comm_broken = false;
+    handles[i]->comm_abort_req.store(false);
+    handles[i]->comm_slot_agreed = 0;
+  }
+  return PT_OK;
+}
+
+int pt_film_accumulate(pt_handle h) {
+  if (!h) return PT_ERR_INVALID_ARGUMENT;
+  PT_HIP(hipSetDevice(h->cfg.device));
+  if (!h->d_film) {
+    PT_HIP(dev_alloc(&h->d_film, (size_t)h->capacity * 3));
+    PT_HIP(hipMemsetAsync(h->d_film, 0, (size_t)h->capacity * 12, h->stream));
+  }
+  if (h->n_items) {
+    hipLaunchKernelGGL(ptd::film_accumulate_kernel, dim3((h->n_items + 255) / 256), dim3(256), 0, h->stream, h->n_items, h->acc, h->d_film, h->tiles);
+    PT_HIP(hipGetLastError());
+  }
+  h->film_steps += 1;
+  return PT_OK;
+}
+
+int pt_film_seed(pt_handle h, const float* host_bgr, size_t n) {
+  if (!h) return PT_ERR_INVALID_ARGUMENT;
+  if (n != h->n_items || (!host_bgr && n)) return fail(h, PT_ERR_INVALID_ARGUMENT, "film seed must cover exactly the current work items");
+  PT_HIP(hipSetDevice(h->cfg.device));
+  if (!h->d_film) {
+    PT_HIP(dev_alloc(&h->d_film, (size_t)h->capacity * 3));
+    PT_HIP(hipMemsetAsync(h->d_film, 0, (size_t)h->capacity * 12, h->stream));
+  }
+  if (n) PT_HIP(hipMemcpyAsync(h->d_film, host_bgr, n * 12, hipMemcpyHostToDevice, h->stream));
+  PT_HIP(hipStreamSynchronize(h->stream));   // host buffer is not touched after return
+  return PT_OK;
+}
+
+int pt_tile_costs_enable(pt_handle h, uint32_t tile_w, uint32_t tile_h) {
+  if (!h) return PT_ERR_INVALID_ARGUMENT;
+  if (tile_w == 0 || tile_h == 0) return fail(h, PT_ERR_INVALID_ARGUMENT, "tile size must be > 0");
+  PT_HIP(hipSetDevice(h->cfg.device));
+  const uint32_t tx = (h->cfg.width + tile_w - 1) / tile_w, ty = (h->cfg.height + tile_h - 1) / tile_h;
+  const uint32_t n = tx * ty;
+  PT_HIP(hipStreamSynchronize(h->stream));
+  if (h->tiles.cost) PT_HIP(hipFree(h->tiles.cost));
+  if (h->d_tile_tmp) PT_HIP(hipFree(h->d_tile_tmp));
+  h->tiles = ptd::TileGrid{};
+  h->d_tile_tmp = nullptr;
+  unsigned long long* cost = nullptr;
+  PT_HIP(dev_alloc(&cost, n));
+  PT_HIP(dev_alloc(&h->d_tile_tmp, n));
+  PT_HIP(hipMemsetAsync(cost, 0, (size_t)n * 8, h->stream));
+  h->tiles.tile_w = tile_w; h->tiles.tile_h = tile_h; h->tiles.tiles_x = tx; h->tiles.n_tiles = n; h->tiles.cost = cost;
+  return PT_OK;
+}
+
+int pt_tile_costs(pt_handle h, uint64_t* host_costs, size_t n_tiles) {
+  if (!h) return PT_ERR_INVALID_ARGUMENT;
+  if (!h->tiles.n_tiles) return fail(h, PT_ERR_NOT_READY, "pt_tile_costs_enable has not been called");
+  if (!host_costs || n_tiles != h->tiles.n_tiles)
+    return fail(h, PT_ERR_INVALID_ARGUMENT, "n_tiles must equal the tile grid's size (" + std::to_string(h->tiles.n_tiles) + ")");
+  PT_HIP(hipSetDevice(h->cfg.device));
+  static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "tile costs are 64-bit");
+  PT_HIP(hipMemcpyAsync(h->d_tile_tmp, h->tiles.cost, n_tiles * 8, hipMemcpyDeviceToDevice, h->stream));
+  if (h->n_items) {
+    ptd::TileGrid T = h->tiles;
+    T.cost = h->d_tile_tmp;
+    hipLaunchKernelGGL(ptd::tile_cost_kernel, dim3((h->n_items + 255) / 256), dim3(256), 0, h->stream, h->n_items, h->acc, T);
+    PT_HIP(hipGetLastError());
+  }
+  PT_HIP(hipMemcpyAsync(host_costs, h->d_tile_tmp, n_tiles * 8, hipMemcpyDeviceToHost, h->stream));
+  PT_HIP(hipStreamSynchronize(h->stream));   // host buffer is not touched after return
+  return PT_OK;
+}
+
+int pt_gather_hdr(pt_handle h, int32_t source, size_t slot_items, float* root_host_bgr) {
+  if (!h) return PT_ERR_INVALID_ARGUMENT;
+  // ---- local steps: everything that can fail without a peer happens before this rank joins the exchange
+  if (h->comm_broken) return fail(h, PT_ERR_COMM, "the communicator of this handle was aborted: create a new one (pt_comm_init_rank / pt_comm_init_all)");
+  if (source != PT_HDR_ACCUMULATORS && source != PT_HDR_FILM) return fail(h, PT_ERR_INVALID_ARGUMENT, "unknown HDR source");
+  if (source == PT_HDR_FILM && !h->d_film) return fail(h, PT_ERR_NOT_READY, "no resident film: pt_film_accumulate has not been called");
+  if (slot_items < h->n_items || slot_items == 0) return fail(h, PT_ERR_INVALID_ARGUMENT, "slot_items must be >= the rank's work items (and > 0)");
+  if (slot_items * 3 >= (1ull << 31)) return fail(h, PT_ERR_INVALID_ARGUMENT, "tile too large");
+  PT_HIP(hipSetDevice(h->cfg.device));
+  const size_t floats = slot_items * 3;
+  if (h->hdr_stage_floats < floats) {
+    if (h->d_hdr_stage) PT_HIP(hipFree(h->d_hdr_stage));
+    h->d_hdr_stage = nullptr; h->hdr_stage_floats = 0;
+    PT_HIP(dev_alloc(&h->d_hdr_stage, floats));
+    h->hdr_stage_floats = floats;
+  }
+  const bool root = h->comm_rank == 0;
+  const size_t world = (size_t)h->comm_world;
+  const bool exchange = h->comm && world > 1;
+  if (root && exchange && h->hdr_gather_floats < world * floats) {
+    if (h->d_hdr_gather) PT_HIP(hipFree(h->d_hdr_gather));
+    h->d_hdr_gather = nullptr; h->hdr_gather_floats = 0;
+    PT_HIP(dev_alloc(&h->d_hdr_gather, world * floats));
+    h->hdr_gather_floats = world * floats;
+  }
+  if (h->n_items < slot_items)
+    PT_HIP(hipMemsetAsync(h->d_hdr_stage + 3 * (size_t)h->n_items, 0, (slot_items - h->n_items) * 12, h->stream));
+  if (h->n_items) {
+    if (source == PT_HDR_FILM) {
+      PT_HIP(hipMemcpyAsync(h->d_hdr_stage, h->d_film, (size_t)h->n_items * 12, hipMemcpyDeviceToDevice, h->stream));
+    } else {
+      hipLaunchKernelGGL(ptd::export_hdr_kernel, dim3((h->n_items + 255) / 256), dim3(256), 0, h->stream, h->n_items, h->acc, h->d_hdr_stage);
+      PT_HIP(hipGetLastError());
+    }
+  }
+  const float* result = h->d_hdr_stage;
+  if (exchange) {
+    const auto deadline = comm_deadline(h);
+    // an RCCL call that fails outright leaves the communicator in an unknown state: abort it (the peers time out)
+#define PT_NCCL_X(call)                                                                                   \
+    do {                                                                                                  \
+      const ncclResult_t r_ = (call);                                                                     \
+      if (r_ != ncclSuccess && r_ != ncclInProgress) return comm_fail(h, std::string(#call) + ": " + ncclGetErrorString(r_)); \
+    } while (0)
+    // ---- the slot size must be the same on every rank (the root's receive counts are its own slot_items): checked
+    // once per communicator and slot size with a max all-reduce of {slot, -slot}; every rank sees the same verdict.
+    // Device -> host copies are only issued on an IDLE stream (after the polled wait): a copy into pageable host memory
+    // blocks the host until the stream reaches it, which must never be behind an exchange a peer may not join.
+    if (h->comm_slot_agreed != slot_items) {
+      const long long mine[2] = {(long long)slot_items, -(long long)slot_items};
+      long long seen[2] = {0, 0};
+      PT_HIP(hipMemcpyAsync(h->d_slot_check, mine, sizeof(mine), hipMemcpyHostToDevice, h->stream));
+      PT_HIP(hipStreamSynchronize(h->stream));   // local work only so far; `mine` may go out of scope
+      PT_NCCL_X(ncclAllReduce(h->d_slot_check, h->d_slot_check, 2, ncclInt64, ncclMax, h->comm, h->stream));
+      if (int rc = comm_wait_host(h, "slot-size agreement", deadline)) return rc;
+      if (int rc = comm_wait_stream(h, "slot-size agreement", deadline)) return rc;
+      PT_HIP(hipMemcpy(seen, h->d_slot_check, sizeof(seen), hipMemcpyDeviceToHost));
+      if (seen[0] != -seen[1])
+        return fail(h, PT_ERR_INVALID_ARGUMENT, "slot_items differs between the ranks of the communicator (" + std::to_string(-seen[1]) +
+                                                    " .. " + std::to_string(seen[0]) + "); this rank passed " + std::to_string(slot_items));
+      h->comm_slot_agreed = slot_items;
+    }
+    // ---- the gather itself
+    if (root) {
+      PT_HIP(hipMemcpyAsync(h->d_hdr_gather, h->d_hdr_stage, floats * 4, hipMemcpyDeviceToDevice, h->stream));
+      PT_NCCL_X(ncclGroupStart());
+      for (size_t r = 1; r < world; ++r) {
+        const ncclResult_t e = ncclRecv(h->d_hdr_gather + r * floats, floats, ncclFloat, (int)r, h->comm, h->stream);
+        if (e != ncclSuccess && e != ncclInProgress) { (void)ncclGroupEnd(); return comm_fail(h, std::string("ncclRecv: ") + ncclGetErrorString(e)); }
+      }
+      PT_NCCL_X(ncclGroupEnd());
+      result = h->d_hdr_gather;
+    } else {
+      PT_NCCL_X(ncclSend(h->d_hdr_stage, floats, ncclFloat, 0, h->comm, h->stream));
+    }
+#undef PT_NCCL_X
+    if (int rc = comm_wait_host(h, "HDR gather", deadline)) return rc;     // peers connected, transfer queued on the stream
+    if (int rc = comm_wait_stream(h, "HDR gather", deadline)) return rc;   // transfer done (or the communicator aborted)
+  } else {
+    PT_HIP(hipStreamSynchronize(h->stream));
+  }
+  if (root && root_host_bgr)   // the stream is idle: this copy cannot wait on anything
+    PT_HIP(hipMemcpy(root_host_bgr, result, world * floats * 4, hipMemcpyDeviceToHost));
+  return PT_OK;
+}
+
+}  // extern "C"
