@@ -61,6 +61,35 @@ def trace_counters_from_profile():
     return None, None
 
 
+def secondary_configs(ptmi, nif_assets, W, H, depth, meta, mean, spp=30):
+    """Two more configurations measured in this run on the same image -- never the bench `value`, reported so that the
+    numbers quoted for them in DESIGN.md / README.md can be checked against a driver-run line: BASELINE config C5 (NIF
+    8 x 1024 fp16, the layer-by-layer path, 14,891,011 FLOP per evaluation) and the same 6 x 320 network with float32
+    variables (the float path, pt_nif_f32.h).  One warm-up step and one timed step of `spp` samples per pixel each."""
+    out = {}
+    for name, kw, peak in (("c5_nif_8x1024_fp16", dict(hidden=1024, layer_count=8), MFMA_F16_DENSE_PEAK_TFLOPS),
+                           ("nif_6x320_float32", dict(hidden=320, layer_count=6, dtype=np.float32), 157.3)):
+        try:
+            L = nif_assets.synthetic_nif(embedding_dim=meta["embedding_dimension"], **kw)
+            r = ptmi.Renderer(W, H, max_path_length=depth)
+            r.init_nif_weights(L, meta["embedding_dimension"], meta["max"], mean)
+            r.init_render_settings(samples_per_step=spp)
+            r.setup(ptmi.worklist(W, H))
+            r.path_trace()
+            t = time.perf_counter()
+            r.path_trace()
+            dt = time.perf_counter() - t
+            st = r.stats()
+            r.close()
+            tf = st.escaped * st.nif_flops_per_sample / (st.nif_ms * 1e-3) / 1e12
+            out[name] = {"value": st.paths / dt / 1e6, "unit": "Mpath-samples/s", "spp_per_step": spp, "ms_per_step": dt * 1e3,
+                         "nif_flops_per_sample": int(st.nif_flops_per_sample), "nif_tflops": tf,
+                         "peak_tflops": peak, "frac": tf / peak}
+        except Exception as e:   # noqa: BLE001 -- a secondary figure must never cost the headline line
+            out[name] = {"error": str(e)}
+    return out
+
+
 def cpu_baseline(width, height, depth, layers, meta, mean, target_seconds=12.0):
     """Time the CPU oracle (a restatement -- upstream external/light is not vendored) on this host's cores,
     on a bounded pixel subset of the same workload at 1 spp."""
@@ -124,6 +153,8 @@ def main():
     ap.add_argument("--hidden", type=int, default=320)
     ap.add_argument("--layers", type=int, default=6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the two secondary measurements (BASELINE config C5, float32 NIF) reported beside the headline")
     # the reference's options of the same names (PathTracerApp.cpp:794-830); defaults keep the headline run unchanged
     ap.add_argument("--save-interval", type=int, default=0,
                     help="gather the HDR tiles to rank 0 every N steps (0: once, after the last timed step)")
@@ -394,6 +425,8 @@ def main():
                                        if pmc.get("hbm_bytes_per_path") else None)
             ts["counters_from"] = "%s (not measured in this run)" % pmc_src
         out["trace_stage"] = ts
+        if world == 1 and not args.no_secondary and not wide:
+            out["secondary"] = secondary_configs(ptmi, nif_assets, W, H, depth, meta, mean)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(W, H, depth, layers, meta, mean)
         if world > 1:
