@@ -137,6 +137,9 @@ bool PathTracerApp::loadNifModels(std::size_t numDevices, const std::string& ass
 }
 
 void PathTracerApp::attach() {
+  if (pt_abi_version() != PTMI_ABI_VERSION)   // built against one include/ptmi.h, running on another libptmi.so
+    throw std::runtime_error("libptmi.so has ABI version " + std::to_string(pt_abi_version()) + ", this host was built against " +
+                             std::to_string(PTMI_ABI_VERSION));
   const auto imageWidth = args.u32("width"), imageHeight = args.u32("height");
   const std::size_t numDevices = args.u32("ipus");
   geometry.numTiles *= numDevices;  // tiles scale with the device count as on a multi-IPU target

@@ -19,6 +19,7 @@ AA_NORMAL, AA_UNIFORM, AA_TRUNCATED_NORMAL = 0, 1, 2
 SAMPLES_HALF, SAMPLES_FLOAT = 0, 1
 DTYPE_F16, DTYPE_F32 = 0, 1
 
+ABI_VERSION = 3          # PTMI_ABI_VERSION of include/ptmi.h this binding was written against
 EXPORTS = ["pt_abi_version", "pt_create", "pt_destroy", "pt_last_error", "pt_upload_nif", "pt_set_constant_env",
            "pt_set_render_settings", "pt_setup", "pt_path_trace", "pt_read_results", "pt_get_stats",
            "pt_export_hdr_device", "pt_clear_accumulators", "pt_synchronize", "pt_nif_infer", "pt_trace_paths",
@@ -79,6 +80,9 @@ def load_library(diag=False):
         pass
     L = C.CDLL(path)
     L.pt_abi_version.restype = C.c_int
+    if L.pt_abi_version() != ABI_VERSION:   # a stale in-tree build: the structs below would not match the library's
+        raise RuntimeError("%s has ABI version %d, this binding needs %d: rebuild it (python -c 'import __graft_entry__ as g; "
+                           "g.build()')" % (path, L.pt_abi_version(), ABI_VERSION))
     L.pt_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
     L.pt_destroy.argtypes = [C.c_void_p]
     L.pt_last_error.restype = C.c_char_p
