@@ -297,7 +297,7 @@ int pt_gather_hdr(pt_handle h, int32_t source, size_t slot_items, float* root_ho
   }
   const bool root = h->comm_rank == 0;
   const size_t world = (size_t)h->comm_world;
-  const bool exchange = h->comm && world > 1;
+  const bool exchange = h->comm != nullptr;   // also at world size 1: the same calls (slot all-reduce, grouped receives -- none --, polled waits) as for N ranks
   if (root && exchange && h->hdr_gather_floats < world * floats) {
     if (h->d_hdr_gather) PT_HIP(hipFree(h->d_hdr_gather));
     h->d_hdr_gather = nullptr; h->hdr_gather_floats = 0;

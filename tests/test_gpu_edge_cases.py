@@ -148,8 +148,10 @@ def test_two_handles_and_seed_semantics(ptmi_lib):
 
 def test_rccl_gather_of_hdr_tiles_single_rank(ptmi_lib):
     """pt_gather_hdr at N = 1 on a real RCCL communicator of one rank (ncclGetUniqueId + ncclCommInitRank inside
-    libptmi.so): the gather degenerates to export + copy, with the slot zero-padded.  N > 1 cannot run on a one-GPU
-    box (RCCL refuses two ranks on one device); the tile placement it feeds is covered by tests/test_partition.py."""
+    libptmi.so): the SAME calls as for N ranks run -- the slot-size all-reduce on the non-blocking communicator, the
+    (empty) group of receives, the polled host and stream waits -- and the result is the rank's own tile, the slot
+    zero-padded.  N > 1 cannot run on a one-GPU box (RCCL refuses two ranks on one device); the tile placement it feeds
+    is covered by tests/test_partition.py."""
     W = H = 48
     r = ptmi_lib.Renderer(W, H, max_path_length=6, max_work_items=W * H + 100)
     r.set_constant_env((0.25, 0.5, 1.0))
