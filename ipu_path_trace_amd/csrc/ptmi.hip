@@ -672,6 +672,37 @@ int pt_diag_inject_fault(pt_handle h, int32_t batch) {
   return PT_OK;
 }
 
+// test build only: the point-to-point half of pt_gather_hdr on a communicator of ONE rank -- a grouped ncclSend / ncclRecv of
+// `floats` floats from this rank to itself on the non-blocking communicator, with the same polled waits as the gather.  A
+// one-GPU box cannot run two ranks (RCCL refuses two ranks on one device); this is as much of the send / receive path as it
+// can execute.  out_ok = 1 if the received buffer equals the sent one.
+int pt_diag_comm_self_exchange(pt_handle h, size_t floats, int* out_ok) {
+  if (!h || !out_ok || floats == 0) return PT_ERR_INVALID_ARGUMENT;
+  if (!h->comm || h->comm_world != 1) return fail(h, PT_ERR_INVALID_ARGUMENT, "needs a communicator of one rank");
+  PT_HIP(hipSetDevice(h->cfg.device));
+  float *src = nullptr, *dst = nullptr;
+  PT_HIP(dev_alloc(&src, floats));
+  PT_HIP(dev_alloc(&dst, floats));
+  std::vector<float> host(floats);
+  for (size_t i = 0; i < floats; ++i) host[i] = (float)(i % 977) * 0.25f - 3.f;
+  PT_HIP(hipMemcpy(src, host.data(), floats * 4, hipMemcpyHostToDevice));
+  PT_HIP(hipMemset(dst, 0, floats * 4));
+  const auto deadline = comm_deadline(h);
+  ncclResult_t r = ncclGroupStart();
+  if (r == ncclSuccess || r == ncclInProgress) r = ncclSend(src, floats, ncclFloat, 0, h->comm, h->stream);
+  if (r == ncclSuccess || r == ncclInProgress) r = ncclRecv(dst, floats, ncclFloat, 0, h->comm, h->stream);
+  const ncclResult_t e = ncclGroupEnd();
+  if (r != ncclSuccess && r != ncclInProgress) return comm_fail(h, std::string("self exchange: ") + ncclGetErrorString(r));
+  if (e != ncclSuccess && e != ncclInProgress) return comm_fail(h, std::string("self exchange: ncclGroupEnd: ") + ncclGetErrorString(e));
+  if (int rc = comm_wait_host(h, "self exchange", deadline)) return rc;
+  if (int rc = comm_wait_stream(h, "self exchange", deadline)) return rc;
+  std::vector<float> back(floats);
+  PT_HIP(hipMemcpy(back.data(), dst, floats * 4, hipMemcpyDeviceToHost));
+  *out_ok = memcmp(back.data(), host.data(), floats * 4) == 0;
+  (void)hipFree(src); (void)hipFree(dst);
+  return PT_OK;
+}
+
 // profiling build only: in-kernel clock of the last stamped fused-NIF launch (nif_kernel_v3 with DIAG bit 5, nif_kernel_v4):
 // out2[0] = shader cycles, out2[1] = 100 MHz ticks of its workgroup 0
 int pt_diag_nif_clock(pt_handle h, unsigned long long* out2) {

@@ -115,6 +115,7 @@ def load_library(diag=False):
         L.pt_diag_inject_fault.argtypes = [C.c_void_p, C.c_int32]
         L.pt_diag_stamps.argtypes = [C.c_void_p, C.c_void_p]
         L.pt_diag_nif_clock.argtypes = [C.c_void_p, C.c_void_p]
+        L.pt_diag_comm_self_exchange.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]
     _libs[diag] = L
     return L
 

@@ -191,6 +191,29 @@ def test_rccl_gather_of_hdr_tiles_single_rank(ptmi_lib):
     r.close()
 
 
+def test_send_and_receive_on_the_non_blocking_communicator(ptmi_lib):
+    """The point-to-point half of pt_gather_hdr (grouped ncclSend / ncclRecv on the non-blocking communicator, completion
+    polled with ncclCommGetAsyncError and hipStreamQuery against the deadline) as far as a one-GPU box can run it: a rank
+    sending 1.2 MB to itself on a communicator of one rank (test build: pt_diag_comm_self_exchange).  The exchange between
+    two ranks needs two GPUs and has never run."""
+    import ctypes as C
+    diag = ptmi_lib.load_library(diag=True)
+    r = ptmi_lib.Renderer(32, 32, max_path_length=4, diag=True)
+    r.comm_set_timeout(30000)
+    r.comm_init_rank(ptmi_lib.comm_unique_id(), 0, 1)
+    ok = C.c_int(0)
+    for floats in (3, 300000):
+        assert diag.pt_diag_comm_self_exchange(r.handle, floats, C.byref(ok)) == 0, diag.pt_last_error(r.handle)
+        assert ok.value == 1
+    # the communicator is still good for the gather afterwards
+    r.set_constant_env((1, 1, 1))
+    r.init_render_settings(samples_per_step=2)
+    r.setup(ptmi_lib.worklist(32, 32))
+    r.path_trace()
+    assert r.gather_hdr(32 * 32).shape == (1, 32 * 32, 3)
+    r.close()
+
+
 def test_failed_path_trace_drains_and_the_handle_stays_usable(oracle, ptmi_lib):
     """A launch failure in the MIDDLE of the batch loop (injected through pt_diag_inject_fault, which exists only in the test
     build libptmi_diag.so -- same sources, -DPTMI_DIAG_BUILD; the product library has no hook) must come back as an error with all
