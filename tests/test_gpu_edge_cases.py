@@ -191,6 +191,37 @@ def test_rccl_gather_of_hdr_tiles_single_rank(ptmi_lib):
     r.close()
 
 
+def test_comm_init_all_for_the_handles_of_one_process(ptmi_lib):
+    """pt_comm_init_all is what `ipu_trace --ipus N` calls (one process driving N GPUs: a group of non-blocking
+    ncclCommInitRankConfig calls, polled per rank).  On a one-GPU box: the group of ONE handle comes up and gathers; two
+    handles on the same GPU are refused by name before anything is created (RCCL needs one device per rank), and both
+    handles stay usable without a communicator."""
+    import ctypes as C
+    lib = ptmi_lib.load_library()
+    W = H = 32
+
+    def renderer():
+        r = ptmi_lib.Renderer(W, H, max_path_length=4)
+        r.set_constant_env((0.5, 0.5, 0.5))
+        r.init_render_settings(samples_per_step=2)
+        r.setup(ptmi_lib.worklist(W, H))
+        r.path_trace()
+        return r
+
+    a, b = renderer(), renderer()
+    two = (C.c_void_p * 2)(a.handle, b.handle)
+    assert lib.pt_comm_init_all(two, 2) == -1                              # PT_ERR_INVALID_ARGUMENT
+    assert b"share device 0" in lib.pt_last_error(a.handle)
+    assert a.comm_info() == (0, 1) and b.comm_info() == (0, 1)
+    one = (C.c_void_p * 1)(a.handle)
+    assert lib.pt_comm_init_all(one, 1) == 0, lib.pt_last_error(a.handle)
+    assert a.comm_info() == (0, 1)
+    ga, gb = a.gather_hdr(W * H), b.gather_hdr(W * H)                      # a: through its communicator; b: without one
+    np.testing.assert_array_equal(ga, gb)
+    assert lib.pt_comm_init_all(one, 1) == -1                              # one communicator per handle
+    a.close(); b.close()
+
+
 def test_send_and_receive_on_the_non_blocking_communicator(ptmi_lib):
     """The point-to-point half of pt_gather_hdr (grouped ncclSend / ncclRecv on the non-blocking communicator, completion
     polled with ncclCommGetAsyncError and hipStreamQuery against the deadline) as far as a one-GPU box can run it: a rank
