@@ -3,6 +3,7 @@ import ctypes as C
 import json
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -695,6 +696,45 @@ def test_cli_on_the_reference_assets_directory(host, tmp_path):
     # without stand-in weights the run fails the way the reference does when converted.hdf5 is missing
     r = subprocess.run([exe, "--assets", os.path.dirname(REAL_META), "-w", "48", "-h", "32", "-o", str(out)], capture_output=True, text=True)
     assert r.returncode == 1 and "Could not load NIF model" in r.stdout
+
+
+@pytest.mark.gpu
+def test_ui_client_script_drives_a_session(host, tmp_path):
+    """scripts/ui_client.py is the usable end of the text protocol (the reference's remote UI speaks packetcomms, absent
+    here): one session of actions against a running `ipu_trace --ui-port` -- change the field of view (a restart), listen,
+    save the latest preview as PPM and the latest complete HDR image as PFM, stop."""
+    import socket
+    exe = os.path.join(HOST, "ipu_trace")
+    assets = tmp_path / "assets.extra"
+    assets.mkdir()
+    nif_assets.write_metadata(str(assets / "nif_metadata.txt"))
+    nif_assets.write_ptnif(str(assets / "converted.ptnif"), nif_assets.synthetic_nif(), 12)
+    W, H = 64, 48
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    proc = subprocess.Popen([exe, "--assets", str(assets), "-w", str(W), "-h", str(H), "-s", "40000000", "--samples-per-step", "20",
+                             "--interactive-samples", "2", "--max-path-length", "5", "-o", str(tmp_path / "ui.png"), "--save-interval", "3",
+                             "--ui-port", str(port)], stdout=open(str(tmp_path / "cli.log"), "w"), stderr=subprocess.STDOUT, text=True)
+    try:
+        c = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "ui_client.py"), "--port", str(port), "--quiet", "--connect-timeout", "120",
+                            "fov=60", "wait=4", "save_preview=" + str(tmp_path / "p.ppm"), "save_hdr=" + str(tmp_path / "p.pfm"), "stop"],
+                           capture_output=True, text=True, timeout=300)
+        assert c.returncode == 0, c.stdout[-2000:] + c.stderr[-2000:]
+        assert proc.wait(timeout=120) == 0
+    finally:
+        if proc.poll() is None:
+            proc.kill()
+    log = open(str(tmp_path / "cli.log")).read()
+    assert "Rendering stopped by remote UI" in log
+    ppm = open(str(tmp_path / "p.ppm"), "rb").read()
+    assert ppm.startswith(b"P6\n%d %d\n255\n" % (W, H)) and len(ppm) == len(b"P6\n%d %d\n255\n" % (W, H)) + W * H * 3
+    pfm = open(str(tmp_path / "p.pfm"), "rb").read()
+    head = b"PF\n%d %d\n-1.0\n" % (W, H)
+    assert pfm.startswith(head) and len(pfm) == len(head) + W * H * 12
+    img = np.frombuffer(pfm[len(head):], dtype="<f4")
+    assert np.isfinite(img).all() and img.max() > 0
 
 
 @pytest.mark.gpu
