@@ -36,6 +36,8 @@
 #include "ptmi_nif_pack.h"
 #include "ptmi_nif_launch.h"
 
+static void comm_release(pt_handle h);   // ptmi_film_comm.h: orderly end of the handle's communicator (finalize, polled; abort on expiry)
+
 extern "C" {
 
 int pt_abi_version(void) { return PTMI_ABI_VERSION; }
@@ -137,7 +139,11 @@ int pt_create(const pt_config* cfg, pt_handle* out) {
 
 int pt_destroy(pt_handle h) {
   if (!h) return PT_OK;
+  (void)hipSetDevice(h->cfg.device);   // ipu_trace --ipus N holds handles of several devices in one process
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  // the communicator goes first, while the streams it has worked on still exist: a non-blocking communicator's teardown is
+  // asynchronous too (ncclCommFinalize, polled against the handle's deadline; ncclCommAbort if it does not finish)
+  comm_release(h);
   free_batch_buffers(h);
   (void)hipFree(h->d_records);
   (void)hipFree(h->acc.pix); (void)hipFree(h->acc.r); (void)hipFree(h->acc.g); (void)hipFree(h->acc.b); (void)hipFree(h->acc.count); (void)hipFree(h->acc.length);
@@ -151,7 +157,6 @@ int pt_destroy(pt_handle h) {
   (void)hipFree(h->d_hdr_stage); (void)hipFree(h->d_hdr_gather); (void)hipFree(h->d_film);
   (void)hipFree(h->d_slot_check);
   (void)hipFree(h->tiles.cost); (void)hipFree(h->d_tile_tmp);
-  if (h->comm) (void)ncclCommDestroy(h->comm);
   for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
   if (h->trace_stream && !h->serial) { (void)hipStreamSynchronize(h->trace_stream); (void)hipStreamDestroy(h->trace_stream); }
   if (h->acc_stream) { (void)hipStreamSynchronize(h->acc_stream); (void)hipStreamDestroy(h->acc_stream); }

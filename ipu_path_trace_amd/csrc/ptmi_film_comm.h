@@ -97,6 +97,31 @@ static int comm_wait_stream(pt_handle h, const char* what, comm_clock::time_poin
 static comm_clock::time_point comm_deadline(pt_handle h) {
   return comm_clock::now() + std::chrono::milliseconds(h->comm_timeout_ms);
 }
+}  // extern "C"
+
+// pt_destroy's half of the communicator's life.  With blocking = 0 ncclCommFinalize / ncclCommDestroy may return
+// ncclInProgress: flush what the communicator still has in flight and wait for it (bounded by the handle's deadline)
+// BEFORE the caller destroys the streams it ran on; a communicator that does not settle in time is aborted instead.
+static void comm_release(pt_handle h) {
+  if (!h->comm) return;
+  const auto deadline = comm_deadline(h);
+  ncclResult_t r = ncclCommFinalize(h->comm);
+  bool settled = (r == ncclSuccess);
+  unsigned spins = 0;
+  while (!settled && (r == ncclSuccess || r == ncclInProgress)) {
+    ncclResult_t st = ncclSuccess;
+    if (ncclCommGetAsyncError(h->comm, &st) != ncclSuccess || (st != ncclSuccess && st != ncclInProgress)) break;
+    if (st == ncclSuccess) { settled = true; break; }
+    if (h->comm_abort_req.load() || comm_clock::now() > deadline) break;
+    comm_backoff(spins);
+  }
+  if (settled) (void)ncclCommDestroy(h->comm);
+  else (void)ncclCommAbort(h->comm);
+  h->comm = nullptr;
+  h->comm_slot_agreed = 0;
+}
+
+extern "C" {
 
 int pt_comm_get_unique_id(void* id_out) {
   static_assert(sizeof(ncclUniqueId) == PT_COMM_ID_BYTES, "PT_COMM_ID_BYTES must match ncclUniqueId");

@@ -99,20 +99,29 @@ std::vector<File::Message> File::objectMessages(std::uint64_t headerAddress) con
   return out;
 }
 
-void File::walkBtree(std::uint64_t node, std::uint64_t heapData, std::map<std::string, std::uint64_t>& out, int depth) const {
-  if (depth > 16) fail("group B-tree is too deep");
+// A node header is 8 bytes + two sibling addresses: no well-formed file holds more nodes than size / that.  Together with
+// "a child sits exactly one level below its parent" this bounds the walk of a crafted file (a cycle of internal nodes would
+// otherwise cost fan-out ^ depth calls).
+void File::checkBtreeNode(int level, int expectLevel, std::size_t& visited, const char* what) const {
+  if (level > 16) fail(std::string(what) + " is too deep");
+  if (expectLevel >= 0 && level != expectLevel) fail(std::string(what) + ": a child node is not one level below its parent");
+  if (++visited > d.size() / (8 + 2 * (std::size_t)sizeOffsets) + 1) fail(std::string(what) + " has more nodes than the file can hold");
+}
+
+void File::walkBtree(std::uint64_t node, std::uint64_t heapData, std::map<std::string, std::uint64_t>& out, int expectLevel, std::size_t& visited) const {
   std::size_t p = (std::size_t)(base + node);
   need(p, 24, "a B-tree node");
   if (std::memcmp(&d[p], "TREE", 4) != 0) fail("bad B-tree node signature");
   if (d[p + 4] != 0) fail("expected a group B-tree");
   const int level = d[p + 5];
+  checkBtreeNode(level, expectLevel, visited, "group B-tree");
   const std::size_t used = u(p + 6, 2);
   std::size_t q = p + 8 + 2 * sizeOffsets;   // past the sibling pointers
   for (std::size_t i = 0; i < used; ++i) {
     q += sizeLengths;                       // key i
     const std::uint64_t child = addr(q);
     q += sizeOffsets;
-    if (level > 0) { walkBtree(child, heapData, out, depth + 1); continue; }
+    if (level > 0) { walkBtree(child, heapData, out, level - 1, visited); continue; }
     std::size_t s = (std::size_t)(base + child);
     need(s, 8, "a symbol table node");
     if (std::memcmp(&d[s], "SNOD", 4) != 0) fail("bad symbol table node signature");
@@ -142,7 +151,8 @@ std::map<std::string, std::uint64_t> File::groupLinks(std::uint64_t headerAddres
     need(hp, 8 + 2 * sizeLengths + sizeOffsets, "a local heap");
     if (std::memcmp(&d[hp], "HEAP", 4) != 0) fail("bad local heap signature");
     const std::uint64_t heapData = addr(hp + 8 + 2 * sizeLengths);
-    walkBtree(btree, heapData, out, 0);
+    std::size_t visited = 0;
+    walkBtree(btree, heapData, out, -1, visited);
   }
   if (!found) fail("object is not a group");
   return out;
@@ -365,15 +375,15 @@ Dataset File::openDataSet(const std::string& path) const {
   return out;
 }
 
-void File::walkChunkBtree(std::uint64_t node, std::size_t nDims, int depth,
+void File::walkChunkBtree(std::uint64_t node, std::size_t nDims, int expectLevel, std::size_t& visited,
                           std::vector<std::pair<std::vector<std::uint64_t>, std::pair<std::uint64_t, std::pair<std::uint32_t, std::uint32_t>>>>& chunks) const {
-  if (depth > 16) fail("chunk B-tree is too deep");
   if (node == kUndefined) return;                      // no chunk was ever written: the dataset reads as zeros
   std::size_t p = (std::size_t)(base + node);
   need(p, 8 + 2 * sizeOffsets, "a chunk B-tree node");
   if (std::memcmp(&d[p], "TREE", 4) != 0) fail("bad chunk B-tree node signature");
   if (d[p + 4] != 1) fail("expected a raw-data-chunk B-tree (node type 1), found type " + std::to_string(d[p + 4]));
   const int level = d[p + 5];
+  checkBtreeNode(level, expectLevel, visited, "chunk B-tree");
   const std::size_t used = u(p + 6, 2);
   const std::size_t keySize = 8 + 8 * nDims;
   std::size_t q = p + 8 + 2 * sizeOffsets;
@@ -384,7 +394,7 @@ void File::walkChunkBtree(std::uint64_t node, std::size_t nDims, int depth,
     for (std::size_t k = 0; k < nDims; ++k) offset[k] = u(q + 8 + 8 * k, 8);
     const std::uint64_t child = addr(q + keySize);
     q += keySize + sizeOffsets;
-    if (level > 0) walkChunkBtree(child, nDims, depth + 1, chunks);
+    if (level > 0) walkChunkBtree(child, nDims, level - 1, visited, chunks);
     else chunks.push_back({std::move(offset), {child, {bytes, mask}}});
     if (chunks.size() > (1u << 22)) fail("too many chunks");
   }
@@ -406,7 +416,8 @@ void File::readChunks(const std::string& path, const ChunkedLayout& layout, cons
   out.bytes.assign(total, 0);                          // chunks never written read as the fill value (zero)
   if (total == 0) return;
   std::vector<std::pair<std::vector<std::uint64_t>, std::pair<std::uint64_t, std::pair<std::uint32_t, std::uint32_t>>>> chunks;
-  walkChunkBtree(layout.btree, rank + 1, 0, chunks);
+  std::size_t visited = 0;
+  walkChunkBtree(layout.btree, rank + 1, -1, visited, chunks);
   std::vector<std::uint8_t> raw, tmp;
   for (const auto& c : chunks) {
     const auto& offset = c.first;
@@ -422,7 +433,11 @@ void File::readChunks(const std::string& path, const ChunkedLayout& layout, cons
         if (raw.size() < 4) fail("chunk of '" + path + "' is too short for its checksum");
         raw.resize(raw.size() - 4);
       } else if (f.id == 1) {                          // deflate
-        tmp.assign(chunkBytes, 0);
+        // a fletcher32 filter applied BEFORE deflate (h5repack -f FLET -f GZIP, older h5py) leaves its four checksum bytes
+        // inside the deflated stream: the inflated chunk is that much longer than the chunk shape
+        std::size_t extra = 0;
+        for (std::size_t fj = 0; fj < fi; ++fj) if (filters[fj].id == 3 && !(mask & (1u << fj))) extra += 4;
+        tmp.assign(chunkBytes + extra, 0);
         uLongf got = (uLongf)tmp.size();
         const int rc = ::uncompress(tmp.data(), &got, raw.data(), (uLong)raw.size());
         if (rc != Z_OK) fail("could not inflate a chunk of '" + path + "' (zlib error " + std::to_string(rc) + ")");

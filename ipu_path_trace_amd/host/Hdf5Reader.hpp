@@ -47,14 +47,16 @@ private:
   void need(std::size_t off, std::size_t n, const char* what) const;
   std::vector<Message> objectMessages(std::uint64_t headerAddress) const;
   std::map<std::string, std::uint64_t> groupLinks(std::uint64_t headerAddress) const;
-  void walkBtree(std::uint64_t node, std::uint64_t heapData, std::map<std::string, std::uint64_t>& out, int depth) const;
+  // expectLevel: -1 at the root (any level up to 16), below it the parent's level - 1; visited: nodes seen so far, bounded by the file size
+  void walkBtree(std::uint64_t node, std::uint64_t heapData, std::map<std::string, std::uint64_t>& out, int expectLevel, std::size_t& visited) const;
+  void checkBtreeNode(int level, int expectLevel, std::size_t& visited, const char* what) const;
   std::uint64_t resolve(const std::string& path) const;
   std::map<std::string, Attribute> attributes(std::uint64_t headerAddress) const;
   std::string globalHeapObject(std::uint64_t collection, std::uint32_t index) const;
   struct Filter { std::uint16_t id; std::vector<std::uint32_t> values; };
   struct ChunkedLayout { std::uint64_t btree = 0; std::vector<std::size_t> dims; };   // dims: chunk shape, then the element size
   void readChunks(const std::string& path, const ChunkedLayout& layout, const std::vector<Filter>& filters, Dataset& out) const;
-  void walkChunkBtree(std::uint64_t node, std::size_t nDims, int depth,
+  void walkChunkBtree(std::uint64_t node, std::size_t nDims, int expectLevel, std::size_t& visited,
                       std::vector<std::pair<std::vector<std::uint64_t>, std::pair<std::uint64_t, std::pair<std::uint32_t, std::uint32_t>>>>& chunks) const;
 
   std::vector<std::uint8_t> d;

@@ -343,6 +343,11 @@ void PathTracerApp::executeResidentFilm(std::uint32_t steps) {
   const std::size_t nTiles = balanceTileCount(imageWidth, imageHeight);
   if (loadBalanceEnabled)
     onEveryDevice("tile costs", [&](std::size_t d) { return pt_tile_costs_enable(devices[d], kBalanceTile, kBalanceTile); });
+  if (slot > itemsPerDevice)
+    // padding items (u = v = 65535) are traced like any other item, as in the reference (LoadBalancer.cpp:66-71); the film and
+    // the tile costs skip them, Samples/sec counts image pixels only, Rays/sec includes them
+    pt_log::info_("Load balancing: {} of {} work items per device are padding ({}%): room for any deal of {} image tiles", slot - itemsPerDevice,
+                  slot, 100.0 * (double)(slot - itemsPerDevice) / (double)slot, nTiles);
 
   for (auto step = 1u; step <= steps; ++step) {
     auto loopStartTime = std::chrono::steady_clock::now();

@@ -79,12 +79,14 @@ class H5Writer:
 
     # ---- objects
     def dataset(self, array, attrs=None, chunks=None, compression=None, shuffle=False, fletcher32=False, filter_ids=None,
-                layout_version=3, leaf_fan=None, skip_chunks=()):
+                layout_version=3, leaf_fan=None, skip_chunks=(), fletcher_first=False, cyclic_index=False):
         """chunks: chunk shape -> chunked layout (edge chunks stored full size, as libhdf5 does).  compression="gzip",
         shuffle, fletcher32: the filter pipeline h5py writes for them, in h5py's order (shuffle, gzip, fletcher32).
         filter_ids: extra filter ids appended to the pipeline message WITHOUT being applied (for rejection tests).
         leaf_fan: entries per B-tree leaf (a second tree level appears when there are more chunks).  skip_chunks: chunk
-        indices left unwritten (they read back as zeros)."""
+        indices left unwritten (they read back as zeros).  fletcher_first: the checksum filter at the head of the pipeline
+        (h5repack -f FLET -f GZIP order) instead of h5py's tail.  cyclic_index: a MALFORMED chunk index whose internal node
+        points at itself through every entry (the reader must refuse it quickly)."""
         a = np.ascontiguousarray(array)
         es = a.dtype.itemsize
         msgs = [self._msg(0x0001, self._dataspace(a.shape)), self._msg(0x0003, self._float_type(es), flags=1)]
@@ -95,11 +97,13 @@ class H5Writer:
         import itertools
         import zlib
         filters = []                                  # (id, client values)
+        if fletcher32 and fletcher_first:
+            filters.append((3, []))
         if shuffle:
             filters.append((2, [es]))
         if compression == "gzip":
             filters.append((1, [4]))
-        if fletcher32:
+        if fletcher32 and not fletcher_first:
             filters.append((3, []))
         entries = []                                  # (offset tuple, address, stored bytes)
         grid = [range(0, s, c) for s, c in zip(a.shape, chunks)]
@@ -130,7 +134,16 @@ class H5Writer:
             body += key(tuple(a.shape), 0)             # the final key
             return self._alloc(body)
 
-        if not entries:
+        if cyclic_index:
+            fan = 64
+            at = self._alloc(b"\0" * (24 + fan * (len(key(entries[0][0], 0)) + 8) + len(key(entries[0][0], 0))))
+            body = b"TREE" + struct.pack("<BBHQQ", 1, 3, fan, UNDEF, UNDEF)
+            for _ in range(fan):
+                body += key(entries[0][0], 0) + struct.pack("<Q", at)
+            body += key(tuple(a.shape), 0)
+            self._patch(at, body)
+            tree = at
+        elif not entries:
             tree = UNDEF
         elif leaf_fan and len(entries) > leaf_fan:
             leaves = [entries[i:i + leaf_fan] for i in range(0, len(entries), leaf_fan)]

@@ -82,6 +82,8 @@ def test_keras_h5_roundtrip(host, tmp_path, vlen, user_block, cap):
     dict(chunks=(32, 32), compression="gzip", shuffle=True),                  # ... with shuffle=True
     dict(chunks=(16, 64), compression="gzip", shuffle=True, fletcher32=True),
     dict(chunks=(64, 64), shuffle=True),
+    dict(chunks=(32, 32), compression="gzip", fletcher32=True, fletcher_first=True),                # h5repack -f FLET -f GZIP order:
+    dict(chunks=(16, 64), compression="gzip", shuffle=True, fletcher32=True, fletcher_first=True),  # checksum bytes inside the deflated stream
 ])
 def test_chunked_and_filtered_datasets(host, tmp_path, opts):
     """Hdf5Model.cpp:96-133 reads the variables through libhdf5, which takes any layout; a Keras file whose weights were
@@ -125,6 +127,22 @@ def test_missing_chunks_read_as_zeros_and_unknown_filters_are_named(host, tmp_pa
         _dataset(host, p, "/zstd")
     with pytest.raises(RuntimeError, match=r"filter 4 \(szip\)"):
         _dataset(host, p, "/szip")
+
+
+def test_a_chunk_index_that_points_at_itself_is_refused_at_once(host, tmp_path):
+    """A crafted chunk B-tree whose internal node lists itself 64 times would cost 64^16 visits under a depth limit alone:
+    a child must sit exactly one level below its parent, and no file holds more nodes than its size allows."""
+    import time
+    from tests.h5_writer import H5Writer
+    a = np.arange(64 * 64, dtype=np.float32).reshape(64, 64)
+    w = H5Writer()
+    root = w.group({"loop": w.dataset(a, chunks=(16, 16), cyclic_index=True)})
+    p = str(tmp_path / "loop.h5")
+    open(p, "wb").write(w.finish(root))
+    t = time.perf_counter()
+    with pytest.raises(RuntimeError, match="one level below its parent"):
+        _dataset(host, p, "/loop")
+    assert time.perf_counter() - t < 1.0
 
 
 def test_unsupported_content_is_reported(host, tmp_path):
