@@ -61,11 +61,12 @@ def trace_counters_from_profile():
     return None, None
 
 
-def secondary_configs(ptmi, nif_assets, W, H, depth, meta, mean, spp=30):
+def secondary_configs(ptmi, nif_assets, W, H, depth, meta, mean, spp=300):
     """Two more configurations measured in this run on the same image -- never the bench `value`, reported so that the
     numbers quoted for them in DESIGN.md / README.md can be checked against a driver-run line: BASELINE config C5 (NIF
     8 x 1024 fp16, the layer-by-layer path, 14,891,011 FLOP per evaluation) and the same 6 x 320 network with float32
-    variables (the float path, pt_nif_f32.h).  One warm-up step and one timed step of `spp` samples per pixel each."""
+    variables (the float path, pt_nif_f32.h).  One warm-up step (30 spp) and one timed step of `spp` samples per pixel -- the
+    300 spp per step BASELINE states -- each."""
     out = {}
     for name, kw, peak in (("c5_nif_8x1024_fp16", dict(hidden=1024, layer_count=8), MFMA_F16_DENSE_PEAK_TFLOPS),
                            ("nif_6x320_float32", dict(hidden=320, layer_count=6, dtype=np.float32), 157.3)):
@@ -73,52 +74,104 @@ def secondary_configs(ptmi, nif_assets, W, H, depth, meta, mean, spp=30):
             L = nif_assets.synthetic_nif(embedding_dim=meta["embedding_dimension"], **kw)
             r = ptmi.Renderer(W, H, max_path_length=depth)
             r.init_nif_weights(L, meta["embedding_dimension"], meta["max"], mean)
-            r.init_render_settings(samples_per_step=spp)
+            r.init_render_settings(samples_per_step=min(spp, 30))
             r.setup(ptmi.worklist(W, H))
             r.path_trace()
+            r.init_render_settings(samples_per_step=spp)
             t = time.perf_counter()
             r.path_trace()
             dt = time.perf_counter() - t
             st = r.stats()
+            kname = r.nif_kernel_name()
             r.close()
             tf = st.escaped * st.nif_flops_per_sample / (st.nif_ms * 1e-3) / 1e12
             out[name] = {"value": st.paths / dt / 1e6, "unit": "Mpath-samples/s", "spp_per_step": spp, "ms_per_step": dt * 1e3,
                          "nif_flops_per_sample": int(st.nif_flops_per_sample), "nif_tflops": tf,
-                         "peak_tflops": peak, "frac": tf / peak}
+                         "peak_tflops": peak, "frac": tf / peak, "kernel": kname}
         except Exception as e:   # noqa: BLE001 -- a secondary figure must never cost the headline line
             out[name] = {"error": str(e)}
     return out
 
 
-def cpu_baseline(width, height, depth, layers, meta, mean, target_seconds=12.0):
-    """Time the CPU oracle (a restatement -- upstream external/light is not vendored) on this host's cores,
-    on a bounded pixel subset of the same workload at 1 spp."""
+def cpu_baseline(ptmi, width, height, depth, layers, meta, mean, target_seconds=12.0):
+    """The CPU beside the GPU number: the oracle's source -- a restatement, upstream
+    external/light is not vendored -- in its TIMING build (oracle/Makefile: -O3 -march=native -fopenmp, contraction allowed,
+    F16C conversions, NIF batches of 64 through a register-blocked AVX2 / AVX-512 kernel), compiled on this host, on all of
+    its cores.  Two legs: `c1` = BASELINE configs[0] in full (256x256, 16 spp, depth 4, constant sky; repeated to fill a few
+    seconds; the GPU's rate on the same config beside it) and `c2_shape` = a bounded pixel sample of the benchmark's own
+    workload (same image, depth and NIF).  The strict build (-ffp-contract=off, the parity checker) is timed on a small
+    sample for reference.  `value` is the c2_shape rate: the same workload as the bench `value`."""
     from oracle import pt_oracle as O
     O.build()
-    nif = O.Nif(layers, meta["embedding_dimension"], meta["max"], mean)
+    fast = O.lib(fast=True)                              # builds libpt_oracle_fast.so for THIS host if need be
+    cores = int(fast.orc_max_threads())
+    info = fast.orc_build_info().decode()
+
+    # ---- c1: 256 x 256, 16 spp, depth 4, constant sky, seed 1 (no NIF)
+    c1_cfg = O.make_config(width=256, height=256, max_path_length=4, env_mode=O.ENV_CONSTANT, env_rgb=(1.0, 1.0, 1.0))
+    work = O.worklist(256, 256)
+    O.render(c1_cfg, None, work, 0, 16, fast=True)      # warm-up (threads, page faults)
+    reps, paths, t = 0, 0, time.perf_counter()
+    while True:
+        st = O.render(c1_cfg, None, work, 16 * (reps + 1), 16, fast=True)
+        reps += 1
+        paths += st.paths
+        dt = time.perf_counter() - t
+        if dt > 3.0 or reps >= 2000:
+            break
+    c1 = {"value": paths / dt / 1e6, "unit": "Mpath-samples/s", "seconds": dt,
+          "sample": "configs[0] in full: 256x256, 16 spp, depth 4, constant sky, %d repetitions" % reps}
+    try:                                                 # the GPU on the same config, for the same table (launch-bound: 1 M paths per step)
+        g = ptmi.Renderer(256, 256, max_path_length=4)
+        g.set_constant_env((1.0, 1.0, 1.0))
+        g.init_render_settings(samples_per_step=16)
+        g.setup(ptmi.worklist(256, 256))
+        g.path_trace()
+        t = time.perf_counter()
+        for _ in range(50):
+            g.path_trace()
+        gdt = time.perf_counter() - t
+        g.close()
+        c1["gpu_value"] = 50 * 256 * 256 * 16 / gdt / 1e6
+        c1["gpu_ms_per_step"] = gdt / 50 * 1e3
+    except Exception as e:   # noqa: BLE001 -- never cost the headline line
+        c1["gpu_error"] = str(e)
+
+    # ---- c2_shape: bounded pixel sample of the benchmark's workload
+    nif = O.Nif(layers, meta["embedding_dimension"], meta["max"], mean, fast=True)
     cfg = O.make_config(width=width, height=height, max_path_length=depth, env_mode=O.ENV_NIF)
     full = O.worklist(width, height)
     rng = np.random.default_rng(0)
-    probe = full[rng.choice(full.size, 20000, replace=False)].copy()
+    probe = full[rng.choice(full.size, min(full.size, 200000), replace=False)].copy()
     t = time.perf_counter()
-    O.render(cfg, nif, probe, 0, 1)
+    O.render(cfg, nif, probe, 0, 1, fast=True)
     rate = probe.size / (time.perf_counter() - t)
-    want = rate * target_seconds
-    n = int(min(full.size, max(20000, want)))
+    n = int(min(full.size, max(20000, rate * target_seconds)))
     sample = full[rng.choice(full.size, n, replace=False)].copy()
-    spp = 1
+    spp = int(min(64, max(1, round(rate * target_seconds / n))))
     t = time.perf_counter()
-    st = O.render(cfg, nif, sample, 0, spp)
+    st = O.render(cfg, nif, sample, 0, spp, fast=True)
     dt = time.perf_counter() - t
-    if dt < 0.5 * target_seconds:                     # many-core hosts finish the whole image at once: add samples,
-        spp = int(min(16, max(2, round(target_seconds / dt))))   # sized from the run just timed, not from the small probe
-        sample["r"] = 0; sample["g"] = 0; sample["b"] = 0; sample["sampleCount"] = 0; sample["pathLength"] = 0
-        t = time.perf_counter()
-        st = O.render(cfg, nif, sample, 0, spp)
-        dt = time.perf_counter() - t
-    return {"value": st.paths / dt / 1e6, "unit": "Mpath-samples/s", "cores": int(O.lib().orc_max_threads()),
-            "kind": "port", "sample": "%d random pixels of the %dx%d image x %d spp, depth %d, same synthetic NIF "
-            "(%.1f s of CPU work)" % (n, width, height, spp, depth, dt)}
+    flops = nif.flops_per_sample()
+    c2 = {"value": st.paths / dt / 1e6, "unit": "Mpath-samples/s", "seconds": dt,
+          "nif_gflops": st.escaped * flops / dt / 1e9,
+          "sample": "%d random pixels of the %dx%d image x %d spp, depth %d, same synthetic NIF" % (n, width, height, spp, depth)}
+
+    # ---- the strict build (the parity checker) on a small sample, for reference
+    snif = O.Nif(layers, meta["embedding_dimension"], meta["max"], mean)
+    small = full[rng.choice(full.size, min(full.size, max(20000, 160 * cores)), replace=False)].copy()
+    t = time.perf_counter()
+    sst = O.render(cfg, snif, small, 0, 1)
+    sdt = time.perf_counter() - t
+    return {"value": c2["value"], "unit": "Mpath-samples/s", "cores": cores, "kind": "port",
+            "sample": c2["sample"] + " (%.1f s of CPU work)" % dt,
+            "build_flags": info, "nproc": os.cpu_count(), "omp_max_threads": cores,
+            "c1": c1, "c2_shape": c2,
+            "strict_build": {"value": sst.paths / sdt / 1e6, "unit": "Mpath-samples/s", "seconds": sdt,
+                             "build_flags": O.lib().orc_build_info().decode(),
+                             "sample": "%d random pixels x 1 spp of the c2_shape workload" % small.size},
+            "what": "the oracle's source (a restatement of the reference's path; upstream external/light is not vendored) in its "
+                    "timing build on this host's cores; never the parity checker"}
 
 
 def spawn_ranks(n):
@@ -160,6 +213,9 @@ def main():
                     help="gather the HDR tiles to rank 0 every N steps (0: once, after the last timed step)")
     ap.add_argument("--enable-load-balancing", action="store_true",
                     help="re-deal image tiles between ranks by measured path length at every save interval")
+    ap.add_argument("--dump-film", default="",
+                    help="rank 0 writes the final film (float32 H x W x 3 BGR, mean radiance) to this .npy file; at one GPU the "
+                         "film takes the same hand-off path (pt_gather_hdr of one tile) -- used by the tests to compare N ranks with one")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be at least 1")
@@ -255,6 +311,8 @@ def main():
     def gather_hdr(n_items):
         """One gather of HDR tiles to rank 0: mean BGR of the current accumulators, [world][slot][3] on rank 0."""
         if world == 1:
+            if args.dump_film:
+                gathered["tiles"] = r.gather_hdr(slot)                  # no communicator: export + copy of the one tile
             return
         if product_gather:
             gathered["tiles"] = r.gather_hdr(slot)                      # export + RCCL gather + copy to the host
@@ -275,13 +333,15 @@ def main():
             gathered["tiles"] = np.stack([p_.cpu().numpy() for p_ in parts])
 
     film_sum = np.zeros((H, W, 3), dtype=np.float64) if rank == 0 else None   # sum over intervals of mean x steps
+    if args.dump_film and world == 1:
+        gathered["via"] = "pt_gather_hdr of one tile (no communicator)"
     state = {"owner": owner, "work": work, "steps_in_interval": 0}
 
     def hand_off(last):
         """Save-interval film hand-off (AccumulatedImage::accumulate, AccumulatedImage.cpp:59-74): mean BGR per work
         item -> one gather of HDR tiles to rank 0; optionally re-deal tiles by path length (N3) and start afresh."""
         gather_hdr(state["work"].size)
-        if rank == 0 and world > 1 and (args.save_interval > 0):
+        if rank == 0 and (world > 1 or args.dump_film) and (args.save_interval > 0):
             film = partition.assemble_hdr(W, H, world, gathered["tiles"], owner=state["owner"])
             film_sum[...] += film.astype(np.float64) * state["steps_in_interval"]
         if last or args.save_interval <= 0:
@@ -346,6 +406,19 @@ def main():
 
     elapsed = max_over_ranks(elapsed)
 
+    # Calibration, same invocation (never `value`): the NIF stage of the last step's largest batch again with nothing beside
+    # it -- same kernel, same resident queue (pt_calibrate_nif).  `nif_alone_tflops` moves with the device (the pool's boxes
+    # differ by 5-7 %); `value_over_alone` = the rate inside the pipelined step / this rate moves only when the pipeline
+    # around the kernel changes.  A slow box lowers both numbers; a regression lowers the ratio.
+    calib = None
+    if rank == 0 and not (world > 1 and rehearsal):
+        try:
+            cal_ms, cal_evals = r.calibrate_nif(launches=4)
+            calib = {"ms_per_launch": cal_ms, "evaluations_per_launch": int(cal_evals), "launches": 4}
+        except ptmi.PtError as e:
+            calib = {"error": str(e)}
+    kernel_name = r.nif_kernel_name()
+
     # Second leg, same invocation: the step as the reference times it (PathTracerApp.cpp:692-694,764-767): programs
     # setup -> path_trace -> read_results, i.e. with the worklist's H2D and D2H copies (20 B per item each way) inside.
     # `value` above keeps the inputs resident, as this benchmark's contract requires; this is the reference's own clock.
@@ -373,8 +446,7 @@ def main():
         nif_s = agg["nif_ms"] * 1e-3
         achieved = agg["escaped"] * flops / nif_s / 1e12 if nif_s > 0 else 0.0
         wide = args.hidden > 320
-        kernel = ("nifg16_layer_kernel<0, 0> (+ encode, the head-fused last layer <1, 0> and the finish kernel per chunk)" if wide
-                  else "nif_kernel_v3<%d, 12, 8, %d, 0>" % (args.hidden, 2 if (args.hidden // 32) % 2 == 0 else 1))
+        kernel = kernel_name                     # reported by the library (pt_nif_kernel_name): what launch_nif dispatched
         traffic, traffic_src = hbm_traffic_from_profile("nifg16_layer_kernel<0" if wide else "nif_kernel_v3<%d" % args.hidden)
         out = {
             "metric": "Mpath-samples/sec @%dx%d, %d spp/step, depth %d" % (W, H, spp, depth),
@@ -425,11 +497,20 @@ def main():
                                        if pmc.get("hbm_bytes_per_path") else None)
             ts["counters_from"] = "%s (not measured in this run)" % pmc_src
         out["trace_stage"] = ts
+        if calib and "error" not in calib:
+            alone_tf = calib["evaluations_per_launch"] * flops / (calib["ms_per_launch"] * 1e-3) / 1e12
+            out["roofline"]["nif_alone_tflops"] = alone_tf
+            out["roofline"]["nif_alone_frac"] = alone_tf / MFMA_F16_DENSE_PEAK_TFLOPS
+            out["roofline"]["value_over_alone"] = achieved / alone_tf if alone_tf > 0 else None
+            out["roofline"]["nif_alone"] = dict(calib, what="pt_calibrate_nif: the NIF stage of the last step's largest batch re-run "
+                                                "alone on the device right after the timed steps (1 untimed + 4 timed launches)")
+        elif calib:
+            out["roofline"]["nif_alone"] = calib
         if world == 1 and not args.no_secondary and not wide:
             out["secondary"] = secondary_configs(ptmi, nif_assets, W, H, depth, meta, mean)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(W, H, depth, layers, meta, mean)
-        if world > 1:
+            out["cpu_baseline"] = cpu_baseline(ptmi, W, H, depth, layers, meta, mean)
+        if world > 1 or args.dump_film:
             if args.save_interval > 0:
                 film = (film_sum / args.steps).astype(np.float32)
                 out["config"]["save_interval"] = args.save_interval
@@ -437,8 +518,11 @@ def main():
             else:
                 film = partition.assemble_hdr(W, H, world, gathered["tiles"])
             out["config"]["hdr_gather"] = gathered["via"]
+            out["config"]["HSA_ENABLE_IPC_MODE_LEGACY"] = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "(unset)")
             out["config"]["film_mean"] = float(film.mean())
             out["config"]["film_nonzero_fraction"] = float((film.sum(axis=2) > 0).mean())
+            if args.dump_film:
+                np.save(args.dump_film, film)
         if rehearsal:
             out["data"] = "synthetic (REHEARSAL on one shared GPU -- not a measurement)"
         print(json.dumps(out), flush=True)

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PTMI_ABI_VERSION 3
+#define PTMI_ABI_VERSION 4
 
 typedef struct pt_context* pt_handle;
 
@@ -148,6 +148,17 @@ int pt_path_trace(pt_handle h);
 int pt_read_results(pt_handle h, pt_trace_record* work, size_t n, pt_stats* stats);
 /* Stats of the last path_trace without the device -> host copy. */
 int pt_get_stats(pt_handle h, pt_stats* stats);
+/* ABI 4.  Name of the NIF kernel(s) the library dispatched for the uploaded model at its last NIF launch (the reference
+ * logs its model through NifModel::analyseModel, NifModel.cpp:122-144; here the kernel choice depends on the shape: fused
+ * register-resident, layer by layer, or float32).  Empty before the first launch.  Always NUL-terminated. */
+int pt_nif_kernel_name(pt_handle h, char* buf, size_t n);
+/* ABI 4.  Calibration of the NIF stage, the counterpart of reading nif_cycle_count (PathTracerApp.cpp:449,598-603) with
+ * nothing else on the device: runs the NIF stage of the largest batch of the LAST pt_path_trace again -- same kernel, same
+ * compacted queue, which is still resident -- one untimed launch and then `launches` timed ones back to back, with no trace
+ * or accumulate kernel beside it.  Returns the average milliseconds per launch (HIP events on the NIF stream) and the
+ * number of NIF evaluations per launch (the queue length).  The worklist's accumulators are not touched.  Comparing this
+ * rate with the one inside a step separates a slow device from a regression of the pipeline around the kernel. */
+int pt_calibrate_nif(pt_handle h, uint32_t launches, double* ms_per_launch, uint64_t* evaluations);
 
 /* Multi-GPU film hand-off.  The path shards over pixels with no exchange of ray data (reference: one NIF
  * replica per IPU, "no inter-ipu exchange of ray data", PathTracerApp.cpp:205-252, shard_utils.cpp:28-38);

@@ -481,6 +481,7 @@ static int enqueue_path_trace(pt_handle h, std::vector<StageSpan>& spans, size_t
         return fail(h, PT_ERR_HIP, "injected fault: NIF launch of batch " + std::to_string(batch));
 #endif
       if (int rc = launch_nif(h, N, h->n_cus)) return rc;
+      B.last_paths = total; B.last_regions = g.blocks; B.last_region_cap = g.region_cap;
       spans.push_back({ev + 2, ev + 3, 1});
       h->stats.nif_launches += 1;
     }
@@ -549,6 +550,53 @@ int pt_path_trace(pt_handle h) {
   float total_ms = 0.f;
   PT_HIP(hipEventElapsedTime(&total_ms, h->events[e_begin_i], h->events[e_end_i]));
   h->stats.total_ms = total_ms;
+  return PT_OK;
+}
+
+int pt_nif_kernel_name(pt_handle h, char* buf, size_t n) {
+  if (!h) return PT_ERR_INVALID_ARGUMENT;
+  if (!buf || n == 0) return fail(h, PT_ERR_INVALID_ARGUMENT, "null name buffer");
+  snprintf(buf, n, "%s", h->nif_kernel.c_str());
+  return PT_OK;
+}
+
+// The NIF stage of the last path_trace's largest batch again, alone on the device: same kernel, same queue (it is still in
+// the batch buffers), same output arrays (rewritten with the same values; the accumulators are not touched).
+int pt_calibrate_nif(pt_handle h, uint32_t launches, double* ms_per_launch, uint64_t* evaluations) {
+  if (!h) return PT_ERR_INVALID_ARGUMENT;
+  if (!ms_per_launch || !evaluations || launches == 0) return fail(h, PT_ERR_INVALID_ARGUMENT, "pt_calibrate_nif: bad arguments");
+  if (!h->nif_valid) return fail(h, PT_ERR_NOT_READY, "pt_upload_nif has not been called");
+  const pt_context::BatchBuffers& B = h->bb[h->bb[1].last_paths > h->bb[0].last_paths ? 1 : 0];
+  if (B.last_paths == 0) return fail(h, PT_ERR_NOT_READY, "no path_trace with a NIF environment has run on this handle yet");
+  PT_HIP(hipSetDevice(h->cfg.device));
+  PT_HIP(hipStreamSynchronize(h->stream));
+  std::vector<uint32_t> counts(B.last_regions);
+  PT_HIP(hipMemcpy(counts.data(), B.region_count, counts.size() * 4, hipMemcpyDeviceToHost));
+  uint64_t evals = 0;
+  for (uint32_t c : counts) evals += c;
+  ptd::NifParams N = h->nif;
+  N.q_u = B.q_u; N.q_v = B.q_v; N.q_tr = B.q_tr; N.q_tg = B.q_tg; N.q_tb = B.q_tb; N.q_path = B.q_path;
+  N.region_count = B.region_count;
+  N.n_regions = B.last_regions;
+  N.region_cap = B.last_region_cap;
+  N.rad_r = B.rad_r; N.rad_g = B.rad_g; N.rad_b = B.rad_b;
+  N.out_bgr = nullptr;
+  hipEvent_t e0 = get_event(h, 0), e1 = get_event(h, 1);
+  if (!e0 || !e1) return fail(h, PT_ERR_HIP, "hipEventCreate failed");
+  if (int rc = launch_nif(h, N, h->n_cus)) return rc;                      // untimed: clocks and caches as inside a step
+  PT_HIP(hipEventRecord(e0, h->stream));
+  int rc = PT_OK;
+  for (uint32_t i = 0; i < launches && rc == PT_OK; ++i) rc = launch_nif(h, N, h->n_cus);
+  PT_HIP(hipEventRecord(e1, h->stream));
+  hipError_t s3 = hipSuccess;
+  for (hipStream_t cs : h->chunk_stream) { const hipError_t e = hipStreamSynchronize(cs); if (e != hipSuccess) s3 = e; }
+  PT_HIP(hipStreamSynchronize(h->stream));
+  if (rc) return rc;
+  if (s3 != hipSuccess) return fail(h, PT_ERR_HIP, std::string("pt_calibrate_nif: ") + hipGetErrorString(s3));
+  float ms = 0.f;
+  PT_HIP(hipEventElapsedTime(&ms, e0, e1));
+  *ms_per_launch = (double)ms / launches;
+  *evaluations = evals;
   return PT_OK;
 }
 

@@ -77,6 +77,8 @@ struct pt_context {
     float *rad_r = nullptr, *rad_g = nullptr, *rad_b = nullptr;
     hipEvent_t traced = nullptr;       // trace kernel of the batch using this set has finished
     hipEvent_t accumulated = nullptr;  // accumulate kernel has consumed this set
+    // geometry of the last batch whose NIF stage ran on this set (pt_calibrate_nif replays the larger one): 0 = none yet
+    uint32_t last_paths = 0, last_regions = 0, last_region_cap = 0;
   } bb[2];
   hipStream_t trace_stream = nullptr;
   hipStream_t acc_stream = nullptr;   // accumulate(b) runs here, so NIF(b+1) follows NIF(b) back to back on `stream`
@@ -113,6 +115,7 @@ struct pt_context {
   uint4* d_wpack = nullptr;
   uint4* d_bpack = nullptr;
   uint64_t nif_flops = 0;
+  std::string nif_kernel;   // what launch_nif dispatched last (pt_nif_kernel_name): the bench line quotes the library, not a guess
   // layer-by-layer path of the wide networks (pt_nif_gemm.h): activation ping-pong and feature pieces of one chunk
   uint4* d_gemm_act[2] = {nullptr, nullptr};
   uint4* d_gemm_feat = nullptr;

@@ -33,6 +33,8 @@ int launch_nif_v2(pt_handle h, const ptd::NifParams& N, int blocks) {
   using G = ptd::NifV2Geometry<HID, E, WAVES>;
   static std::atomic<unsigned long long> attr_set{0};
   if (int rc = set_dynamic_lds(h, reinterpret_cast<const void*>(&ptd::nif_kernel_v2<HID, E, NB, WAVES>), G::LDS_BYTES, attr_set)) return rc;
+  static const std::string name = "nif_kernel_v2<" + std::to_string(HID) + ", " + std::to_string(E) + ", " + std::to_string(NB) + ", " + std::to_string(WAVES) + ">";
+  h->nif_kernel = name;
   hipLaunchKernelGGL((ptd::nif_kernel_v2<HID, E, NB, WAVES>), dim3(blocks), dim3(64 * WAVES), G::LDS_BYTES, h->stream, N);
   PT_HIP(hipGetLastError());
   return PT_OK;
@@ -43,6 +45,8 @@ int launch_nif_v3(pt_handle h, const ptd::NifParams& N, int blocks) {
   using G = ptd::NifV3Geometry<HID, E, WAVES, TPS>;
   static std::atomic<unsigned long long> attr_set{0};
   if (int rc = set_dynamic_lds(h, reinterpret_cast<const void*>(&ptd::nif_kernel_v3<HID, E, WAVES, TPS, DIAG>), G::LDS_BYTES, attr_set)) return rc;
+  static const std::string name = "nif_kernel_v3<" + std::to_string(HID) + ", " + std::to_string(E) + ", " + std::to_string(WAVES) + ", " + std::to_string(TPS) + ", " + std::to_string(DIAG) + ">";
+  h->nif_kernel = name;
   hipLaunchKernelGGL((ptd::nif_kernel_v3<HID, E, WAVES, TPS, DIAG>), dim3(blocks), dim3(64 * WAVES), G::LDS_BYTES, h->stream, N);
   PT_HIP(hipGetLastError());
   return PT_OK;
@@ -324,6 +328,8 @@ int launch_nif_gemm(pt_handle h, const ptd::NifParams& N) {
   G.n_ftiles = NT;
   G.head_piece_base = h->head_piece_base;
   G.partial_stride = chunk * 32u;
+  h->nif_kernel = "nifg16_layer_kernel<0, 0> x " + std::to_string(n_layers - 2) + " + nifg16_layer_kernel<1, 0> (last hidden layer, head fused) + nifg16_encode_kernel<" +
+                  std::to_string(h->nif_emb) + "> + nifg16_finish_kernel, per chunk of " + std::to_string(chunk) + " queue tiles, hidden " + std::to_string(H);
   const uint32_t lh = n_layers - 1;
   ptd::NifHeadParams Hd{};
   Hd.slices = 2u * FB;
@@ -442,6 +448,8 @@ void launch_nif32_encode(pt_handle h, hipStream_t st, const ptd::NifParams& N, u
 int launch_nif_f32(pt_handle h, const ptd::NifParams& N) {
   const uint32_t chunk = h->f32_chunk, n_layers = (uint32_t)h->f32_layers.size();
   if (!chunk) return fail(h, PT_ERR_NOT_READY, "float32 NIF buffers are not allocated");
+  h->nif_kernel = "nif32_layer_kernel x " + std::to_string(n_layers - 1) + " + nif32_encode_kernel<" + std::to_string(h->nif_emb) + "> + nif32_head_kernel, per chunk of " +
+                  std::to_string(chunk) + " queue tiles, hidden " + std::to_string(h->nif_hidden);
   hipLaunchKernelGGL(ptd::nifg_scan_kernel, dim3(1), dim3(256), 0, h->stream, N.region_count, N.n_regions, h->d_tile_start);
   PT_HIP(hipGetLastError());
   const uint64_t max_tiles = (uint64_t)N.n_regions * ((N.region_cap + 31u) / 32u);
@@ -490,6 +498,7 @@ int launch_nif_f32(pt_handle h, const ptd::NifParams& N) {
 }
 
 int launch_nif(pt_handle h, const ptd::NifParams& N, int blocks) {
+  h->nif_kernel = "(profiling-build variant)";   // every product launcher below overwrites it with the kernel it dispatches
   if (h->nif_f32) return launch_nif_f32(h, N);
   if (h->nif_gemm) {
 #ifdef PTMI_DIAG_BUILD

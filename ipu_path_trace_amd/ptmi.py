@@ -19,12 +19,13 @@ AA_NORMAL, AA_UNIFORM, AA_TRUNCATED_NORMAL = 0, 1, 2
 SAMPLES_HALF, SAMPLES_FLOAT = 0, 1
 DTYPE_F16, DTYPE_F32 = 0, 1
 
-ABI_VERSION = 3          # PTMI_ABI_VERSION of include/ptmi.h this binding was written against
+ABI_VERSION = 4          # PTMI_ABI_VERSION of include/ptmi.h this binding was written against
 EXPORTS = ["pt_abi_version", "pt_create", "pt_destroy", "pt_last_error", "pt_upload_nif", "pt_set_constant_env",
            "pt_set_render_settings", "pt_setup", "pt_path_trace", "pt_read_results", "pt_get_stats",
            "pt_export_hdr_device", "pt_clear_accumulators", "pt_synchronize", "pt_nif_infer", "pt_trace_paths",
            "pt_comm_get_unique_id", "pt_comm_init_rank", "pt_comm_init_all", "pt_comm_info", "pt_comm_set_timeout", "pt_comm_abort",
-           "pt_gather_hdr", "pt_film_accumulate", "pt_tile_costs_enable", "pt_tile_costs", "pt_film_seed"]
+           "pt_gather_hdr", "pt_film_accumulate", "pt_tile_costs_enable", "pt_tile_costs", "pt_film_seed",
+           "pt_nif_kernel_name", "pt_calibrate_nif"]
 COMM_ID_BYTES = 128
 HDR_ACCUMULATORS, HDR_FILM = 0, 1
 
@@ -111,6 +112,8 @@ def load_library(diag=False):
     L.pt_synchronize.argtypes = [C.c_void_p]
     L.pt_nif_infer.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     L.pt_trace_paths.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.pt_nif_kernel_name.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    L.pt_calibrate_nif.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     if diag:
         L.pt_diag_inject_fault.argtypes = [C.c_void_p, C.c_int32]
         L.pt_diag_stamps.argtypes = [C.c_void_p, C.c_void_p]
@@ -218,6 +221,19 @@ class Renderer:
         st = Stats()
         self._check(self._lib.pt_get_stats(self.handle, C.byref(st)))
         return st
+
+    def nif_kernel_name(self):
+        """The NIF kernel(s) the library dispatched at its last NIF launch ('' before the first)."""
+        buf = C.create_string_buffer(512)
+        self._check(self._lib.pt_nif_kernel_name(self.handle, buf, len(buf)))
+        return buf.value.decode()
+
+    def calibrate_nif(self, launches=4):
+        """The NIF stage of the last path_trace's largest batch again, alone on the device.
+        Returns (milliseconds per launch, NIF evaluations per launch)."""
+        ms, evals = C.c_double(), C.c_uint64()
+        self._check(self._lib.pt_calibrate_nif(self.handle, launches, C.byref(ms), C.byref(evals)))
+        return ms.value, evals.value
 
     def export_hdr_device(self, device_ptr, n):
         self._check(self._lib.pt_export_hdr_device(self.handle, C.c_void_p(device_ptr), n))

@@ -73,7 +73,21 @@ float orc_h2f(uint16_t h) {
   return u2f(sign | ((e + 112u) << 23) | (m << 13));
 }
 
+#ifdef ORC_FAST_BUILD
+/* TIMING BUILD (oracle/Makefile target libpt_oracle_fast.so: -O3 -march=native -fopenmp, contraction allowed): the same
+ * source as the parity checker, compiled the way BASELINE.md section 3 / SURVEY.md 8(d) time a CPU baseline.  Only the
+ * cpu_baseline leg of bench.py and tests/test_oracle_fast.py load it; it is never the parity checker.  What changes:
+ * binary16 rounding through F16C (same RNE results), the NIF matmul as a register-blocked AVX2 / AVX-512 kernel over
+ * batches of 64 samples (per output the same k-ordered FMA chain, so the NIF stays bit-identical to the strict build),
+ * and the compiler may contract a*b+c in the trace arithmetic (paths can differ from the strict build in the last ulp). */
+#include <immintrin.h>
+#if !defined(__F16C__) || !defined(__AVX2__) || !defined(__FMA__)
+#error "the timing build needs F16C, AVX2 and FMA (-march=native on any x86-64-v3 host)"
+#endif
+static inline float hround(float f) { return _cvtsh_ss(_cvtss_sh(f, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC)); }
+#else
 static inline float hround(float f) { return orc_h2f(orc_f2h(f)); }
+#endif
 
 /* ------------------------------------------------------------------ RNG
  * The IPU's hardware RNG streams (poprand, PathTracerApp.cpp:29-45,285-299,333-336) cannot be
@@ -673,7 +687,81 @@ void orc_nif_encode(uint32_t emb, float u, float v, float* f) {
   }
 }
 
+#ifdef ORC_FAST_BUILD
+#define NIF_BATCH 64
+#else
 #define NIF_BATCH 16
+#endif
+
+#ifdef ORC_FAST_BUILD
+/* One dense layer over a batch, timing build: y[b][n] = epilogue(sum_k x[b][k] * Wt[k][n]) with the sum formed as ONE
+ * FMA chain in k order per (b, n) from 0 -- exactly the strict build's fmaf loop below -- but with the accumulators of a
+ * (samples x 16 outputs) block held in registers and the block's weight panel (K x 16 floats = 20 KB at K = 320) reused
+ * from L1 across the batch.  Epilogue as the reference's rounding points: round to half, + bias in half, ReLU. */
+#if defined(__AVX512F__)
+#define ORC_MB 12
+#else
+#define ORC_MB 6
+#endif
+static inline __m256 hround8(__m256 v) { return _mm256_cvtph_ps(_mm256_cvtps_ph(v, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC)); }
+static void nif_layer_fast(const orc_nif* m, uint32_t l, const float* x, float* y, int B, uint32_t W) {
+  const uint32_t K = m->rows[l], N = m->cols[l];
+  const float* Wt = m->kernel[l];
+  const float* bias = m->bias[l];
+  const int f32 = m->f32, has_bias = m->has_bias[l], relu = m->relu[l];
+  uint32_t n0 = 0;
+  for (; n0 + 16 <= N; n0 += 16) {
+    for (int b0 = 0; b0 < B; b0 += ORC_MB) {
+      const int mb = (B - b0 < ORC_MB) ? B - b0 : ORC_MB;
+      const float* xr[ORC_MB];
+      for (int i = 0; i < ORC_MB; ++i) xr[i] = x + (size_t)(b0 + (i < mb ? i : 0)) * W;   /* tail rows repeat row 0 (not stored) */
+#if defined(__AVX512F__)
+      __m512 acc[ORC_MB];
+      for (int i = 0; i < ORC_MB; ++i) acc[i] = _mm512_setzero_ps();
+      for (uint32_t k = 0; k < K; ++k) {
+        const __m512 w = _mm512_loadu_ps(Wt + (size_t)k * N + n0);
+        for (int i = 0; i < ORC_MB; ++i) acc[i] = _mm512_fmadd_ps(_mm512_set1_ps(xr[i][k]), w, acc[i]);
+      }
+      __m256 lo[ORC_MB], hi[ORC_MB];
+      for (int i = 0; i < ORC_MB; ++i) { lo[i] = _mm512_castps512_ps256(acc[i]); hi[i] = _mm512_extractf32x8_ps(acc[i], 1); }
+#else
+      __m256 lo[ORC_MB], hi[ORC_MB];
+      for (int i = 0; i < ORC_MB; ++i) { lo[i] = _mm256_setzero_ps(); hi[i] = _mm256_setzero_ps(); }
+      for (uint32_t k = 0; k < K; ++k) {
+        const __m256 w0 = _mm256_loadu_ps(Wt + (size_t)k * N + n0), w1 = _mm256_loadu_ps(Wt + (size_t)k * N + n0 + 8);
+        for (int i = 0; i < ORC_MB; ++i) {
+          const __m256 xv = _mm256_broadcast_ss(xr[i] + k);
+          lo[i] = _mm256_fmadd_ps(xv, w0, lo[i]);
+          hi[i] = _mm256_fmadd_ps(xv, w1, hi[i]);
+        }
+      }
+#endif
+      const __m256 b_lo = _mm256_loadu_ps(bias + n0), b_hi = _mm256_loadu_ps(bias + n0 + 8), zero = _mm256_setzero_ps();
+      for (int i = 0; i < mb; ++i) {
+        __m256 o0 = lo[i], o1 = hi[i];
+        if (!f32) { o0 = hround8(o0); o1 = hround8(o1); }                       /* matmul output type = kernel type (:314) */
+        if (has_bias) {                                                          /* addInPlace :316-321 */
+          o0 = _mm256_add_ps(o0, b_lo); o1 = _mm256_add_ps(o1, b_hi);
+          if (!f32) { o0 = hround8(o0); o1 = hround8(o1); }
+        }
+        if (relu) { o0 = _mm256_max_ps(o0, zero); o1 = _mm256_max_ps(o1, zero); }   /* !(o > 0) -> 0, NaN included */
+        _mm256_storeu_ps(y + (size_t)(b0 + i) * W + n0, o0);
+        _mm256_storeu_ps(y + (size_t)(b0 + i) * W + n0 + 8, o1);
+      }
+    }
+  }
+  for (; n0 < N; ++n0)                                                           /* ragged tail (the 3-wide head) */
+    for (int b = 0; b < B; ++b) {
+      float a = 0.f;
+      for (uint32_t k = 0; k < K; ++k) a = fmaf(x[(size_t)b * W + k], Wt[(size_t)k * N + n0], a);
+      float o = f32 ? a : hround(a);
+      if (has_bias) o = f32 ? o + bias[n0] : hround(o + bias[n0]);
+      if (relu && !(o > 0.f)) o = 0.f;
+      y[(size_t)b * W + n0] = o;
+    }
+}
+#endif
+
 /* x: [B][max_width] activations (fp16 values held in float). */
 static void nif_forward(const orc_nif* m, const float* u, const float* v, int B, float* bgr,
                         float* bufA, float* bufB, float* input) {
@@ -685,13 +773,18 @@ static void nif_forward(const orc_nif* m, const float* u, const float* v, int B,
   }
   float* x = bufA; float* y = bufB;
   uint32_t xcols = in_dim;
+#ifndef ORC_FAST_BUILD
   float acc[NIF_BATCH][1024 + 8];
+#endif
   for (uint32_t l = 0; l < m->n_layers; ++l) {
     uint32_t K = m->rows[l], N = m->cols[l];
     if (xcols != K) {                                   /* NifModel.cpp:305-308 */
       for (int b = 0; b < B; ++b) memcpy(x + (size_t)b * W + xcols, input + (size_t)b * in_dim, in_dim * 4);
       xcols += in_dim;
     }
+#ifdef ORC_FAST_BUILD
+    nif_layer_fast(m, l, x, y, B, W);
+#else
     const float* Wt = m->kernel[l];
     for (uint32_t n0 = 0; n0 < N; n0 += 1024) {
       uint32_t nn = (N - n0 < 1024) ? N - n0 : 1024;
@@ -711,6 +804,7 @@ static void nif_forward(const orc_nif* m, const float* u, const float* v, int B,
         y[(size_t)b * W + n0 + n] = o;
       }
     }
+#endif
     float* t = x; x = y; y = t;
     xcols = N;
   }
@@ -808,6 +902,24 @@ int orc_render(const orc_config* cfg, const orc_nif* nif, orc_trace_record* rec,
   }
   if (stats) { stats->paths = (uint64_t)n * n_samples; stats->segments = segs; stats->escaped = esc; }
   return 0;
+}
+
+/* Which build this is: "strict" (the parity checker) or the timing build's compiler flags. */
+const char* orc_build_info(void) {
+#ifdef ORC_FAST_BUILD
+#ifdef ORC_BUILD_FLAGS
+  return "timing build: " ORC_BUILD_FLAGS
+#else
+  return "timing build"
+#endif
+#if defined(__AVX512F__)
+         " [AVX-512 12x16 NIF block]";
+#else
+         " [AVX2 6x16 NIF block]";
+#endif
+#else
+  return "strict: -O3 -ffp-contract=off -fno-fast-math (parity checker)";
+#endif
 }
 
 int orc_max_threads(void) {

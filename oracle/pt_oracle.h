@@ -115,6 +115,7 @@ int orc_trace_records(const orc_config*, uint16_t u, uint16_t v, uint32_t sample
 int orc_render(const orc_config*, const orc_nif*, orc_trace_record* records, size_t n,
                uint32_t sample_base, uint32_t n_samples, orc_stats* stats);
 int orc_max_threads(void);
+const char* orc_build_info(void);   /* "strict ..." or the timing build's flags (libpt_oracle_fast.so) */
 
 /* ---- building blocks exposed for known-answer tests ---- */
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);

@@ -12,6 +12,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libpt_oracle.so")
+_FAST_PATH = os.path.join(_HERE, "libpt_oracle_fast.so")
+_FAST_STAMP = os.path.join(_HERE, "libpt_oracle_fast.stamp")
 
 
 def build(force=False):
@@ -20,6 +22,39 @@ def build(force=False):
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libpt_oracle.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
+
+
+def _host_stamp():
+    """What -march=native depends on: this host's CPU flags (and the source's age)."""
+    import hashlib
+    flags = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    flags = line
+                    break
+    except OSError:
+        pass
+    src = os.path.join(_HERE, "pt_oracle.c")
+    return hashlib.sha256((flags + str(os.path.getmtime(src))).encode()).hexdigest()
+
+
+def build_fast(force=False):
+    """The TIMING build of the same source (oracle/Makefile: -O3 -march=native -fopenmp, -DORC_FAST_BUILD) -- only for the
+    cpu_baseline leg of bench.py and its own CPU test; never the parity checker.  -march=native is host-specific, so the
+    library is rebuilt whenever it was made for a host with other CPU flags (a .so built in the container travels to the
+    GPU box, whose CPU is a different one)."""
+    stamp = _host_stamp()
+    old = None
+    if os.path.exists(_FAST_STAMP):
+        with open(_FAST_STAMP) as f:
+            old = f.read().strip()
+    if force or not os.path.exists(_FAST_PATH) or old != stamp:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libpt_oracle_fast.so"], stdout=subprocess.DEVNULL)
+        with open(_FAST_STAMP, "w") as f:
+            f.write(stamp)
+    return _FAST_PATH
 
 
 class TraceRecord(C.Structure):
@@ -62,14 +97,25 @@ FOLD_BACKWARD, FOLD_FORWARD = 0, 1
 DIFFUSE, EMIT, ESCAPED, REFRACT, SPECULAR, DEBUG, END, SKIP = range(8)
 
 _lib = None
+_fast_lib = None
 
 
-def lib():
-    global _lib
+def lib(fast=False):
+    """fast=False: the strict build, the parity checker.  fast=True: the timing build (build_fast)."""
+    global _lib, _fast_lib
+    if fast:
+        if _fast_lib is None:
+            _fast_lib = _bind(C.CDLL(build_fast()))
+        return _fast_lib
     if _lib is None:
         if not os.path.exists(_LIB_PATH):
             build()
-        L = C.CDLL(_LIB_PATH)
+        _lib = _bind(C.CDLL(_LIB_PATH))
+    return _lib
+
+
+def _bind(L):
+    if True:
         fp = C.POINTER(C.c_float)
         L.orc_nif_create.restype = C.c_void_p
         L.orc_nif_create.argtypes = [C.POINTER(Layer), C.c_uint32, C.c_uint32, C.c_float, fp, C.c_int32]
@@ -112,8 +158,9 @@ def lib():
         L.orc_aa_noise.argtypes = [C.POINTER(Config), C.c_uint16, C.c_uint16, C.c_uint32, C.c_void_p]
         L.orc_scene_object.argtypes = [C.c_int, C.c_void_p, fp, C.c_void_p, C.POINTER(C.c_int32)]
         L.orc_object_ids.argtypes = [C.c_uint32, C.c_uint32, C.c_float, C.c_void_p]
-        _lib = L
-    return _lib
+        L.orc_build_info.restype = C.c_char_p
+        L.orc_max_threads.restype = C.c_int
+    return L
 
 
 def make_config(width=256, height=256, max_path_length=10, roulette_depth=3, stop_prob=0.3,
@@ -141,8 +188,9 @@ class Nif:
     float32 runs in float (the reference gives a matmul its kernel's type, NifModel.cpp:314); anything else is a float16
     model (float32 entries are rounded to binary16, as the device library does for a float32 layer inside a float16 model)."""
 
-    def __init__(self, layers, embedding_dim, max_value, mean_folded, log_tonemap=True):
+    def __init__(self, layers, embedding_dim, max_value, mean_folded, log_tonemap=True, fast=False):
         self._keep = []
+        self._lib = lib(fast)
         arr = (Layer * len(layers))()
         self.float32 = all(np.asarray(k).dtype == np.float32 for k, _, _ in layers)
         dt = np.float32 if self.float32 else np.float16
@@ -157,26 +205,26 @@ class Nif:
                 arr[i].bias = b.ctypes.data
             arr[i].relu = int(bool(relu))
         mean = (C.c_float * 3)(*[float(x) for x in mean_folded])
-        create = lib().orc_nif_create_f32 if self.float32 else lib().orc_nif_create
+        create = self._lib.orc_nif_create_f32 if self.float32 else self._lib.orc_nif_create
         self.handle = create(arr, len(layers), embedding_dim, float(max_value), mean, int(log_tonemap))
         self.embedding_dim = embedding_dim
 
     def __del__(self):
         if getattr(self, "handle", None):
-            lib().orc_nif_destroy(self.handle)
+            self._lib.orc_nif_destroy(self.handle)
             self.handle = None
 
     def infer(self, u, v):
         u = np.ascontiguousarray(u, dtype=np.float32)
         v = np.ascontiguousarray(v, dtype=np.float32)
         out = np.empty((u.size, 3), dtype=np.float32)
-        rc = lib().orc_nif_infer(self.handle, u.ctypes.data, v.ctypes.data, u.size, out.ctypes.data)
+        rc = self._lib.orc_nif_infer(self.handle, u.ctypes.data, v.ctypes.data, u.size, out.ctypes.data)
         if rc:
             raise RuntimeError("orc_nif_infer failed: %d" % rc)
         return out
 
     def flops_per_sample(self):
-        return int(lib().orc_nif_flops_per_sample(self.handle))
+        return int(self._lib.orc_nif_flops_per_sample(self.handle))
 
 
 def nif_encode(embedding_dim, u, v):
@@ -199,11 +247,13 @@ def trace_records(cfg, u, v, sample, capacity=64):
     return types[:n], clr[:n], w[:n]
 
 
-def render(cfg, nif, records, sample_base, n_samples):
-    """records: numpy array of TRACE_DTYPE, updated in place.  Returns Stats."""
+def render(cfg, nif, records, sample_base, n_samples, fast=False):
+    """records: numpy array of TRACE_DTYPE, updated in place.  Returns Stats.  fast=True: the timing build (the NIF, if any,
+    must have been created with fast=True as well)."""
     assert records.dtype == TRACE_DTYPE and records.flags.c_contiguous
+    assert nif is None or nif._lib is lib(fast), "a Nif belongs to the build that created it"
     st = Stats()
-    rc = lib().orc_render(C.byref(cfg), nif.handle if nif is not None else None, records.ctypes.data, records.size,
+    rc = lib(fast).orc_render(C.byref(cfg), nif.handle if nif is not None else None, records.ctypes.data, records.size,
                           sample_base, n_samples, C.byref(st))
     if rc:
         raise RuntimeError("orc_render failed: %d" % rc)

@@ -755,6 +755,16 @@ def test_cli_multi_device_loop_on_one_gpu(host, tmp_path):
     two_host, log = _run_cli(host, tmp_path, "two_host", ["--ipus", "2", "--devices", "0,0", "--host-film"], steps=5)
     assert "the reference's" in log
     assert two_host.tobytes() == one.tobytes()
+    # BASELINE config C4's world size: 8 devices (8 handles, 8 host threads, 8 worklist slices and resident films, an 8-way
+    # tile deal by measured path length at every save interval, 8 HDR tiles per gather) -- on one GPU, one process
+    zeros8 = ",".join(["0"] * 8)
+    one_big, _ = _run_cli(host, tmp_path, "one_big", ["--ipus", "1"], W=176, H=144, steps=5)
+    eight, log = _run_cli(host, tmp_path, "eight", ["--ipus", "8", "--devices", zeros8], W=176, H=144, steps=5)
+    assert "HDR tiles of 8 devices are gathered through the host" in log
+    assert eight.tobytes() == one_big.tobytes()
+    eight_lb, log = _run_cli(host, tmp_path, "eight_lb", ["--ipus", "8", "--devices", zeros8, "--enable-load-balancing"], W=176, H=144, steps=5)
+    assert log.count("Load balancing finished") == 2 and "99 image tiles over 8 devices" in log and "are padding" in log
+    assert eight_lb.tobytes() == one_big.tobytes()
     # a list that does not match --ipus, or is not a list of ordinals, is refused before anything is attached
     exe = os.path.join(HOST, "ipu_trace")
     for bad in ("0", "0,x", "0,-1"):

@@ -55,6 +55,38 @@ def test_bench_two_ranks_started_by_bench_itself():
     assert "REHEARSAL" in out["data"]                              # and nobody can take it for a measurement
 
 
+@pytest.mark.gpu
+def test_bench_rehearsal_of_c4_four_ranks_film_equals_one_rank(tmp_path):
+    """BASELINE config C4's job shape through bench.py itself, started the way the driver starts it: N ranks, a save
+    interval, tiles re-dealt between the ranks by measured path length, one gather of HDR tiles per interval.  The film rank 0
+    assembles must equal the one-rank film of the same sample indices BIT FOR BIT (RNG keyed by pixel and absolute sample
+    index; per-pixel fp32 sums in iteration order whichever rank owns the pixel).  Four ranks, not C4's eight: every rank
+    is a process holding GPU 0, and the pool's GPU boxes allow six processes on the card at once, this test process
+    included (the driver's own 8-GPU node runs one rank per GPU).  World size 8 itself is covered where one process can do
+    it -- tests/test_host.py::test_cli_multi_device_loop_on_one_gpu (ipu_trace --ipus 8 --devices 0 x 8) -- and on the CPU
+    (tests/test_partition.py, 8 gloo ranks)."""
+    import numpy as np
+    common = ["--steps", "2", "--warmup", "1", "--samples-per-step", "8", "--save-interval", "1", "--no-cpu-baseline",
+              "--no-secondary", "--width", "368", "--height", "272"]
+    films = {}
+    for n, extra in ((1, []), (4, ["--enable-load-balancing"])):
+        path = str(tmp_path / ("film%d.npy" % n))
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--dump-film", path] + common + extra,
+                           capture_output=True, text=True, timeout=900, env=_clean_env(BENCH_REHEARSAL="1"), cwd=ROOT)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+        lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, p.stdout[-2000:]
+        out = json.loads(lines[0])
+        assert out["n_gpus"] == n and out["steps"] == 2
+        assert out["config"]["film_nonzero_fraction"] > 0.99
+        if n > 1:
+            assert out["config"]["load_balancing"] is True and out["config"]["save_interval"] == 1
+            assert "HSA_ENABLE_IPC_MODE_LEGACY" in out["config"]         # which IPC mode the ranks ran with is on record
+            assert "REHEARSAL" in out["data"]
+        films[n] = np.load(path)
+    assert films[4].shape == (272, 368, 3) and films[4].tobytes() == films[1].tobytes()
+
+
 _LONE_RANK = textwrap.dedent("""
     import sys, time
     sys.path.insert(0, %r)

@@ -128,13 +128,14 @@ dist.destroy_process_group()
 """
 
 
-def test_hdr_gather_two_ranks_gloo(tmp_path):
+@pytest.mark.parametrize("world", [2, 8])   # 8 = BASELINE config C4's world size (8 CPU processes, gloo)
+def test_hdr_gather_ranks_gloo(tmp_path, world):
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
            "127.0.0.1", "--master-port", str(port), str(script), ROOT]
     env = dict(os.environ, OMP_NUM_THREADS="1")
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
