@@ -117,6 +117,18 @@ __device__ __forceinline__ void glds16x2(const void* sbase, uint32_t lane_off, u
       : "memory");
 }
 
+// The same with the non-temporal bit on both loads (profiling build, the wide-NIF activation stream: a line marked for
+// early replacement in L2 should not push out the layer's weights).
+__device__ __forceinline__ void glds16x2_nt(const void* sbase, uint32_t lane_off, uint32_t lds_byte_addr) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2 nt\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024 nt\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(lane_off), "s"(reinterpret_cast<uint64_t>(sbase)), "s"(lds_byte_addr)
+      : "memory");
+}
+
 template <int H, int E, int NB, int WAVES>
 __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void nif_kernel_v2(const NifParams P) {
   using G = NifV2Geometry<H, E, WAVES>;

@@ -199,7 +199,8 @@ __global__ __launch_bounds__(512, 2) void nifg16_layer_kernel(const NifGemmParam
                    : "=&v"(d0), "=&v"(d1) : "v"(lane16), "s"(reinterpret_cast<uint64_t>(base)) : "memory");
       asm volatile("" ::"v"(d0), "v"(d1));
     } else if constexpr (!(DIAG & 1) && !(DIAG & 128)) {
-      glds16x2(base, lane16, dst);
+      if constexpr ((DIAG & 8192) != 0) glds16x2_nt(base, lane16, dst);   // bit 13 (valid results): non-temporal activation loads
+      else glds16x2(base, lane16, dst);
     }
     advance(pb, RB);
   };

@@ -31,11 +31,13 @@ def totals(folder, kernel="trace_kernel"):
 def main():
     tag = sys.argv[1]
     src = os.path.join(ROOT, "gpurun_out", tag)
+    depth = int(open(os.path.join(src, "depth")).read()) if os.path.exists(os.path.join(src, "depth")) else 8
     sq, n = totals(os.path.join(src, "sq"))
     fetch, _ = totals(os.path.join(src, "fetch"))
     write, _ = totals(os.path.join(src, "write"))
-    doc = {"source": "scripts/pmc_trace.sh %s: rocprofv3 --pmc passes over scripts/trace_bench.py 8 (constant sky, 1104x1000, 2 x 64 spp, "
-                     "depth 8); totals over %d trace_kernel dispatches / %d paths" % (tag, n, PATHS),
+    doc = {"source": "scripts/pmc_trace.sh %s: rocprofv3 --pmc passes over scripts/trace_bench.py %d (constant sky, 1104x1000, 2 x 64 spp, "
+                     "depth %d); totals over %d trace_kernel dispatches / %d paths" % (tag, depth, depth, n, PATHS),
+           "max_path_length": depth,
            "paths": PATHS, "dispatches": n, "totals": sq}
     if "SQ_INSTS_VALU" in sq:
         doc["valu_wave_instr_per_path"] = sq["SQ_INSTS_VALU"] / PATHS          # wave-level instructions (64 lanes each)

@@ -763,7 +763,7 @@ def test_cli_multi_device_loop_on_one_gpu(host, tmp_path):
     assert "HDR tiles of 8 devices are gathered through the host" in log
     assert eight.tobytes() == one_big.tobytes()
     eight_lb, log = _run_cli(host, tmp_path, "eight_lb", ["--ipus", "8", "--devices", zeros8, "--enable-load-balancing"], W=176, H=144, steps=5)
-    assert log.count("Load balancing finished") == 2 and "99 image tiles over 8 devices" in log and "are padding" in log
+    assert log.count("Load balancing finished") == 2 and "99 image tiles over 8 devices" in log
     assert eight_lb.tobytes() == one_big.tobytes()
     # a list that does not match --ipus, or is not a list of ordinals, is refused before anything is attached
     exe = os.path.join(HOST, "ipu_trace")
