@@ -53,10 +53,11 @@ def hbm_traffic_from_profile(kernel_prefix):
     return None, None
 
 
-def trace_counters_from_profile():
-    """Wave-level VALU instructions per path of trace_kernel, from the committed PMC pass of scripts/pmc_trace.sh."""
+def trace_counters_from_profile(depth=8):
+    """Wave-level VALU instructions per path of trace_kernel, from the committed PMC pass of scripts/pmc_trace.sh taken at
+    this --max-path-length (files without the field are depth 8)."""
     for doc, path in _profiles("r*_trace_pmc.json"):
-        if "valu_wave_instr_per_path" in doc:
+        if "valu_wave_instr_per_path" in doc and doc.get("max_path_length", 8) == depth:
             return doc, path
     return None, None
 
@@ -479,7 +480,7 @@ def main():
         }
         # Trace stage (ray-gen, intersect, shade, compact; accumulate is its own kernel).  Everything here is measured in
         # this run except the two per-path constants, which come from the named PMC file.
-        pmc, pmc_src = trace_counters_from_profile()
+        pmc, pmc_src = trace_counters_from_profile(depth)
         alone_s = alone.path_trace_ms * 1e-3
         ts = {"bound": "valu", "unit": "G wave-instructions/s", "peak": VALU_PEAK_GWAVE_INSTR,
               "standalone_ms_per_step": alone.path_trace_ms, "standalone_accumulate_ms_per_step": alone.accumulate_ms,

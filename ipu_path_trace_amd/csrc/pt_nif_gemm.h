@@ -97,6 +97,12 @@ __device__ __forceinline__ uint32_t chunk_tile_count(const uint32_t* total_tiles
 //   waves 4-7 (one phase late)     B-pair, read    MFMA q0(S)      A-pair, wait,   MFMA q1(S)      B-pair, read
 //                                  A, B (S)                        read A'(S)                      A, B (S+1)
 //
+// Round 4: the streams no longer push the weights out of L2.  One XCD runs 8 sample blocks x 4 feature blocks at a time; between
+// two uses of a weight line (one block, ~25 us) its L2 (4 MiB) saw 8 x (512 KiB of activations in + 512 KiB out), so every
+// sample block fetched the layer's 2 MiB of weights again (FETCH + WRITE 671.6 MB per hidden layer = 1.25 x algorithmic).  The
+// activation loads now carry `nt` and the output stores `sc1` (write-through, line dropped): 563.7 MB = 1.05 x algorithmic, +1.2 %
+// (profiles/r04_c5_ablation.txt; either hint alone: +0.4 % / see there).  DIAG bits 13 / 10 / 11 switch them back for the A/B.
+//
 // Where the time goes (round 3, profiles/r03_c5_ablation.txt: in-kernel s_memtime / s_memrealtime stamps, timing-only
 // builds).  With every load redirected to an L2-hot piece the kernel needs exactly the cycles it needs with no loads at all
 // (MFMA pipe 78 % busy inside a block) -- the LDS-DMA issue, the ring and the barriers cost no cycles -- but runs at
@@ -105,8 +111,8 @@ __device__ __forceinline__ uint32_t chunk_tile_count(const uint32_t* total_tiles
 // 2.0-2.1 GHz: the chip is power-limited either way.  Tried against the activation stalls, all within +-0.5 %: an
 // activation ring one slot deeper than the weight ring ("B leads": RB = 5, DIAG bit 9 selects it; a wave's vector-memory
 // operations retire in order, so the counted wait for stage S + 1 covers every older load and B can lead A by one stage
-// at most), write-through (sc1) or non-temporal output stores (bits 10 / 11), chunks small enough for both activation
-// buffers to stay in the Infinity Cache.  One workgroup taking the four feature blocks of its sample block in turn
+// at most), write-through (sc1) or non-temporal output stores ALONE (round 4: together with nt loads they are worth
+// +1.2 %), chunks small enough for both activation buffers to stay in the Infinity Cache.  One workgroup taking the four feature blocks of its sample block in turn
 // instead of four neighbours sharing them through L2 (bit 12): 16 % slower.
 //
 // q0 = feature tiles 0-3 of the wave x its four sample tiles, q1 = feature tiles 4-7 x the same four (the B fragments
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(512, 2) void nifg16_layer_kernel(const NifGemmParam
   if (blk_sb(0) >= nsb) return;                            // nothing for this workgroup (uniform)
   const uint32_t nst = P.ks_act + P.ks_in;                 // stages = k-steps
 
-  // (DIAG bits 10 / 11: the output stores through a buffer descriptor, for their cache-policy bits)
+  // the output stores go through a buffer descriptor, for their cache-policy bits
   const auto out_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(P.act_out ? P.act_out : P.act_in), 0, 0x7fffffff, 0x00020000);
   const uint32_t relu_floor = P.relu ? 0u : 0xfc00fc00u;   // packed fp16 pair
   unsigned long long t_cycles = 0, t_real = 0;
@@ -199,7 +205,8 @@ __global__ __launch_bounds__(512, 2) void nifg16_layer_kernel(const NifGemmParam
                    : "=&v"(d0), "=&v"(d1) : "v"(lane16), "s"(reinterpret_cast<uint64_t>(base)) : "memory");
       asm volatile("" ::"v"(d0), "v"(d1));
     } else if constexpr (!(DIAG & 1) && !(DIAG & 128)) {
-      if constexpr ((DIAG & 8192) != 0) glds16x2_nt(base, lane16, dst);   // bit 13 (valid results): non-temporal activation loads
+      // the activation stream is read once: non-temporal, so that its lines are the first to leave L2 (bit 13: plain loads)
+      if constexpr ((DIAG & 8192) == 0) glds16x2_nt(base, lane16, dst);
       else glds16x2(base, lane16, dst);
     }
     advance(pb, RB);
@@ -336,16 +343,13 @@ __global__ __launch_bounds__(512, 2) void nifg16_layer_kernel(const NifGemmParam
           hacc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hw, o, hacc[b], 0, 0, 0);
         } else {
           const uint32_t t16 = sb * 16u + 4u * wn + b;
-          if constexpr ((DIAG & 3072) != 0) {   // bit 10: sc1 (write-through, the line is not kept in L2), bit 11: nt
+          {   // sc1 = write-through: the line does not stay in L2 (the next layer reads it in another launch, long after it
+              // would have been evicted anyway).  Bit 10: plain stores, bit 11: nt stores.
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
             union { half8 hh; u32x4 u; } c1;
             c1.hh = o;
             const uint32_t off = ((((t16 >> 1) * P.act_stride + j) * 2u + (t16 & 1u)) * 64u + (uint32_t)lane) * 16u;
-            __builtin_amdgcn_raw_buffer_store_b128(c1.u, out_rsrc, off, 0, (DIAG & 1024) ? 16 : 2);
-          } else {
-            union { half8 hh; uint4 u; } c0;
-            c0.hh = o;
-            P.act_out[(((size_t)(t16 >> 1) * P.act_stride + j) * 2u + (t16 & 1u)) * 64u + lane] = c0.u;
+            __builtin_amdgcn_raw_buffer_store_b128(c1.u, out_rsrc, off, 0, (DIAG & 1024) ? 0 : (DIAG & 2048) ? 2 : 16);
           }
         }
       }

@@ -300,7 +300,7 @@ int launch_nifg16_layer(pt_handle h, hipStream_t st, const ptd::NifGemmParams& G
     return PT_OK;                                                                                                              \
   }
   switch (gdiag) { PT_LAYER16(1) PT_LAYER16(2) PT_LAYER16(3) PT_LAYER16(8) PT_LAYER16(32) PT_LAYER16(64) PT_LAYER16(128) PT_LAYER16(256)
-                   PT_LAYER16(16) PT_LAYER16(33) PT_LAYER16(40) PT_LAYER16(48) PT_LAYER16(160) PT_LAYER16(512) PT_LAYER16(544) PT_LAYER16(1024) PT_LAYER16(2048) PT_LAYER16(1056) PT_LAYER16(4096) PT_LAYER16(5120) PT_LAYER16(8192) PT_LAYER16(9216) PT_LAYER16(10240) default: break; }
+                   PT_LAYER16(16) PT_LAYER16(33) PT_LAYER16(40) PT_LAYER16(48) PT_LAYER16(160) PT_LAYER16(512) PT_LAYER16(544) PT_LAYER16(1024) PT_LAYER16(2048) PT_LAYER16(1056) PT_LAYER16(4096) PT_LAYER16(5120) PT_LAYER16(8192) PT_LAYER16(9216) PT_LAYER16(3072) default: break; }
 #undef PT_LAYER16
 #endif
   hipLaunchKernelGGL((ptd::nifg16_layer_kernel<FUSE, 0>), dim3(grid), dim3(512), ptd::kGemmLdsBytes, st, G);
