@@ -73,8 +73,8 @@ typedef struct pt_config {
 
 /* One dense layer as NifModel streams it (src/neural_networks/DenseLayer.hpp:18-31,
  * NifModel.cpp:375-401): kernel row-major [rows = in][cols = out], bias [cols] or NULL,
- * raw fp16 or fp32 bytes as stored in the Keras H5 (Hdf5Model.cpp:109-133 accepts both; float32 models are slow: the
- * fp32 matrix rate is 1/16 of the fp16 one).
+ * raw fp16 or fp32 bytes as stored in the Keras H5 (Hdf5Model.cpp:109-133 accepts both; models with float32 layers are
+ * slow: the fp32 matrix rate is 1/16 of the fp16 one).
  * Any Dense stack the reference's rule accepts is taken: first layer 4*embedding -> h0, every
  * later layer's input width either the previous width or that + 4*embedding (concat(x, input),
  * NifModel.cpp:305-308), head with 3 outputs; 2..16 layers, embedding 1..16, widths <= 2048. */
@@ -82,9 +82,10 @@ typedef struct pt_layer {
   uint32_t rows, cols;
   const void* kernel;
   const void* bias;
-  int32_t dtype;                 /* PT_DTYPE_F16 or PT_DTYPE_F32.  A model ALL of whose layers are float32 runs in float, as the
-                                  * reference gives a matmul its kernel's type (NifModel.cpp:314); a float32 layer inside a
-                                  * float16 model is rounded to binary16 on upload */
+  int32_t dtype;                 /* PT_DTYPE_F16 or PT_DTYPE_F32.  Every layer runs in the type of its own kernel, as the reference
+                                  * gives a matmul its kernel's type (NifModel.cpp:314): a model with any float32 layer takes the
+                                  * float path (fp32 matrix rate), where its binary16 layers round their sums and add their bias
+                                  * in half and read their input cast to half; an all-binary16 model takes the fp16 kernels */
   int32_t relu;                  /* activation == "relu" (NifModel.cpp:323-325) */
 } pt_layer;
 

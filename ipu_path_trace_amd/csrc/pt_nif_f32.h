@@ -34,6 +34,9 @@ struct NifF32Params {
   uint32_t ldw;              // padded output width (multiple of 32)
   uint32_t k_act, k_in;      // inputs taken from the previous activations / from the Fourier features (multiples of 16)
   uint32_t relu;
+  uint32_t half_out;         // this layer's variables are binary16 (a mixed model): the matmul output is rounded to half and the
+                             // bias is added in half (NifModel.cpp:314-321, a matmul takes its kernel's type)
+  uint32_t cast_half;        // the NEXT layer is binary16 and this one is not: the activations it reads are cast to half
   const float* act_in;       // packed, width lda
   const float* feat;         // packed, width ldf
   float* act_out;            // packed, width ldw
@@ -123,8 +126,11 @@ __device__ __forceinline__ void nif32_mfma_stage(const NifF32Stage& S, const flo
 // from sinking them to the first use, the scheduling barrier stops the machine scheduler.
 #define NIF32_PIN() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
-// Bias, activation and the packed store of a block's accumulators.
-template <bool TWO, bool RELU>
+__device__ __forceinline__ float nif32_hround(float x) { return (float)(_Float16)x; }   // RNE, subnormals kept: v_cvt_f16_f32 / v_cvt_f32_f16
+
+// Bias, activation and the packed store of a block's accumulators.  MODE (mixed models only): 1 = this layer is binary16
+// (round the sum to half, add the bias in half), 2 = cast the result to half for a binary16 layer that follows a float one.
+template <bool TWO, bool RELU, int MODE = 0>
 __device__ __forceinline__ void nif32_store(const NifF32Params& P, const f32x16 (&acc)[2][2], uint32_t tl, uint32_t f0, uint32_t lane) {
   float4 b[2][4];              // all bias loads first: a load issued between the stores would wait for every store before it
 #pragma unroll
@@ -140,9 +146,16 @@ __device__ __forceinline__ void nif32_store(const NifF32Params& P, const f32x16 
       const uint32_t f = f0 + 32u * u + 8u * q + 4u * (lane >> 5);
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        float4 o = make_float4(acc[t][u][4 * q] + b[u][q].x, acc[t][u][4 * q + 1] + b[u][q].y, acc[t][u][4 * q + 2] + b[u][q].z,
-                               acc[t][u][4 * q + 3] + b[u][q].w);      // addInPlace (:316-321)
+        float4 o;
+        if constexpr (MODE == 1) {   // matmul output in half, + bias in half (zero where the layer has none: x + 0 rounds to x)
+          o = make_float4(nif32_hround(nif32_hround(acc[t][u][4 * q]) + b[u][q].x), nif32_hround(nif32_hround(acc[t][u][4 * q + 1]) + b[u][q].y),
+                          nif32_hround(nif32_hround(acc[t][u][4 * q + 2]) + b[u][q].z), nif32_hround(nif32_hround(acc[t][u][4 * q + 3]) + b[u][q].w));
+        } else {
+          o = make_float4(acc[t][u][4 * q] + b[u][q].x, acc[t][u][4 * q + 1] + b[u][q].y, acc[t][u][4 * q + 2] + b[u][q].z,
+                          acc[t][u][4 * q + 3] + b[u][q].w);      // addInPlace (:316-321)
+        }
         if (RELU) { o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f; o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f; }   // (:323-325)
+        if constexpr (MODE == 2) o = make_float4(nif32_hround(o.x), nif32_hround(o.y), nif32_hround(o.z), nif32_hround(o.w));
         *reinterpret_cast<float4*>(P.act_out + nif32_packed(tl + t, P.ldw, f >> 3, lane)) = o;
       }
     }
@@ -192,7 +205,13 @@ __device__ __forceinline__ void nif32_block(const NifF32Params& P, float (*slice
     *reinterpret_cast<float4*>(&slice[(it + 1u) & 1u][wr][wc]) = wn;   // read last in iteration it - 1, before its barrier
     __syncthreads();
   }
-  if (P.relu) nif32_store<TWO, true>(P, acc, tl, f0, lane);
+  if (P.half_out) {        // mixed models only (uniform branches)
+    if (P.relu) nif32_store<TWO, true, 1>(P, acc, tl, f0, lane);
+    else nif32_store<TWO, false, 1>(P, acc, tl, f0, lane);
+  } else if (P.cast_half) {
+    if (P.relu) nif32_store<TWO, true, 2>(P, acc, tl, f0, lane);
+    else nif32_store<TWO, false, 2>(P, acc, tl, f0, lane);
+  } else if (P.relu) nif32_store<TWO, true>(P, acc, tl, f0, lane);
   else nif32_store<TWO, false>(P, acc, tl, f0, lane);
 }
 
@@ -217,6 +236,7 @@ struct NifF32Head {
   const float* w;            // [k_act + k_in][4]
   float bias0, bias1, bias2;
   uint32_t k_act, k_in, relu;
+  uint32_t half_out;         // the head's variables are binary16 (a mixed model): sum rounded to half, bias added in half
   const float* act_in; const float* feat;
   uint32_t lda, ldf;
   uint32_t tile0, chunk_tiles;
@@ -254,7 +274,7 @@ __global__ __launch_bounds__(256) void nif32_head_kernel(const NifParams P, cons
     float bgr[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      float o = acc[k] + bias[k];
+      float o = Hd.half_out ? nif32_hround(nif32_hround(acc[k]) + bias[k]) : acc[k] + bias[k];
       if (Hd.relu) o = o > 0.f ? o : 0.f;
       o = o * P.max;
       o = o + mean[k];

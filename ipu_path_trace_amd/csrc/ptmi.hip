@@ -170,16 +170,33 @@ int pt_destroy(pt_handle h) {
   return PT_OK;
 }
 
-// A model all of whose layers are float32: the float path (pt_nif_f32.h).
+// A model with float32 layers: the float path (pt_nif_f32.h).  Every layer runs in the type of ITS kernel, as the reference
+// gives a matmul its kernel's type (NifModel.cpp:314): a binary16 layer of a mixed model is widened exactly (fp16 -> fp32 is
+// lossless, and a product of two halves is exact in float), its sum is rounded to half and its bias added in half, and the
+// activations it reads are cast to half first -- the fp32 FMA chain in k order is then the same sum the fp16 kernels'
+// oracle forms.  Such a model runs at the fp32 matrix rate throughout.
 static int upload_nif_f32(pt_handle h, const pt_layer* layers, uint32_t n_layers, uint32_t embedding_dim, float max,
                           const float mean[3], int32_t log_tonemap) {
   std::vector<HostLayerF32> L(n_layers);
   uint64_t flops = 0;
   for (uint32_t l = 0; l < n_layers; ++l) {
     L[l].rows = layers[l].rows; L[l].cols = layers[l].cols; L[l].relu = layers[l].relu != 0; L[l].has_bias = layers[l].bias != nullptr;
-    const float* kp = static_cast<const float*>(layers[l].kernel);
-    L[l].kernel.assign(kp, kp + (size_t)L[l].rows * L[l].cols);
-    if (layers[l].bias) { const float* bp = static_cast<const float*>(layers[l].bias); L[l].bias.assign(bp, bp + L[l].cols); }
+    L[l].f16 = layers[l].dtype == PT_DTYPE_F16;
+    const size_t count = (size_t)L[l].rows * L[l].cols;
+    if (L[l].f16) {
+      const uint16_t* kp = static_cast<const uint16_t*>(layers[l].kernel);
+      L[l].kernel.resize(count);
+      for (size_t i = 0; i < count; ++i) L[l].kernel[i] = host_h2f(kp[i]);
+      if (layers[l].bias) {
+        const uint16_t* bp = static_cast<const uint16_t*>(layers[l].bias);
+        L[l].bias.resize(L[l].cols);
+        for (uint32_t i = 0; i < L[l].cols; ++i) L[l].bias[i] = host_h2f(bp[i]);
+      }
+    } else {
+      const float* kp = static_cast<const float*>(layers[l].kernel);
+      L[l].kernel.assign(kp, kp + count);
+      if (layers[l].bias) { const float* bp = static_cast<const float*>(layers[l].bias); L[l].bias.assign(bp, bp + L[l].cols); }
+    }
     flops += 2ull * L[l].rows * L[l].cols + (layers[l].bias ? L[l].cols : 0);  // NifModel.cpp:129-133
   }
   std::vector<float> blob;
@@ -235,36 +252,25 @@ int pt_upload_nif(pt_handle h, const pt_layer* layers, uint32_t n_layers, uint32
   if (!layers || !mean || n_layers == 0) return fail(h, PT_ERR_INVALID_ARGUMENT, "null NIF arguments");
   std::vector<HostLayer> L(n_layers);
   uint64_t flops = 0;
-  bool all_f32 = true;
+  bool any_f32 = false;
   for (uint32_t l = 0; l < n_layers; ++l) {
     if (layers[l].dtype != PT_DTYPE_F16 && layers[l].dtype != PT_DTYPE_F32)
       return fail(h, PT_ERR_UNSUPPORTED_MODEL, "NIF weights must be float16 or float32");
     if (!layers[l].kernel || layers[l].rows == 0 || layers[l].cols == 0) return fail(h, PT_ERR_INVALID_ARGUMENT, "empty layer kernel");
-    all_f32 = all_f32 && layers[l].dtype == PT_DTYPE_F32;
+    any_f32 = any_f32 || layers[l].dtype == PT_DTYPE_F32;
   }
-  if (all_f32) return upload_nif_f32(h, layers, n_layers, embedding_dim, max, mean, log_tonemap);
+  if (any_f32) return upload_nif_f32(h, layers, n_layers, embedding_dim, max, mean, log_tonemap);   // each layer in its own type
   for (uint32_t l = 0; l < n_layers; ++l) {
     L[l].rows = layers[l].rows;
     L[l].cols = layers[l].cols;
     L[l].relu = layers[l].relu != 0;
     const size_t count = (size_t)L[l].rows * L[l].cols;
-    if (layers[l].dtype == PT_DTYPE_F16) {
+    {
       const uint16_t* kp = static_cast<const uint16_t*>(layers[l].kernel);
       L[l].kernel.assign(kp, kp + count);
       if (layers[l].bias) {
         const uint16_t* bp = static_cast<const uint16_t*>(layers[l].bias);
         L[l].bias.assign(bp, bp + L[l].cols);
-      }
-    } else {
-      // a float32 layer inside a float16 model (the reference would run that one layer in float; a model all of whose
-      // layers are float32 takes the float path, upload_nif_f32): rounded to binary16 (RNE) here -- DESIGN.md section 2
-      const float* kp = static_cast<const float*>(layers[l].kernel);
-      L[l].kernel.resize(count);
-      for (size_t i = 0; i < count; ++i) L[l].kernel[i] = host_f2h(kp[i]);
-      if (layers[l].bias) {
-        const float* bp = static_cast<const float*>(layers[l].bias);
-        L[l].bias.resize(L[l].cols);
-        for (uint32_t i = 0; i < L[l].cols; ++i) L[l].bias[i] = host_f2h(bp[i]);
       }
     }
     flops += 2ull * L[l].rows * L[l].cols + (layers[l].bias ? L[l].cols : 0);  // NifModel.cpp:129-133

@@ -100,7 +100,7 @@ struct pt_context {
   bool nif_gemm32 = false;   // profiling build: the round-2 32x32x16 layer kernels (diag/pt_nif_gemm32.h) for the A/B
   // float32 models (pt_nif_f32.h): padded row-major kernels and biases of all layers in one buffer, chunk buffers
   bool nif_f32 = false;
-  struct F32Layer { size_t w_off, b_off; uint32_t k_act, k_in, ldw, relu; };
+  struct F32Layer { size_t w_off, b_off; uint32_t k_act, k_in, ldw, relu, half_out, cast_half; };
   std::vector<F32Layer> f32_layers;
   float* d_f32_weights = nullptr;
   float* d_f32_act[2] = {nullptr, nullptr};

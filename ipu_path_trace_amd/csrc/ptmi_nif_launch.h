@@ -384,7 +384,7 @@ int launch_nif_gemm(pt_handle h, const ptd::NifParams& N) {
 // ---- float32 models (pt_nif_f32.h) -----------------------------------------------------------------------------
 // Shapes as normalize_nif: hidden widths padded to a common multiple of 32 (zero weights, zero bias), the Fourier features
 // to 4 x Ep with Ep = E rounded up to a multiple of 4 (zero rows for the padding slots, zero features).
-struct HostLayerF32 { uint32_t rows, cols; std::vector<float> kernel, bias; bool has_bias, relu; };
+struct HostLayerF32 { uint32_t rows, cols; std::vector<float> kernel, bias; bool has_bias, relu, f16 = false; };   // f16: binary16 variables, widened (a mixed model)
 
 int pack_nif_f32(pt_handle h, const std::vector<HostLayerF32>& L, uint32_t E, std::vector<float>& blob,
                  std::vector<pt_context::F32Layer>& out, uint32_t& Hp_out, uint32_t& Ep_out) {
@@ -418,6 +418,8 @@ int pack_nif_f32(pt_handle h, const std::vector<HostLayerF32>& L, uint32_t E, st
     F.k_in = (l == 0 || concat) ? in_p : 0u;
     F.ldw = head ? 4u : Hp;
     F.relu = Y.relu;
+    F.half_out = Y.f16 ? 1u : 0u;
+    F.cast_half = (!Y.f16 && !head && L[l + 1].f16) ? 1u : 0u;   // a binary16 layer reads its input as half (its matmul's type)
     F.w_off = blob.size();
     blob.resize(blob.size() + (size_t)(F.k_act + F.k_in) * F.ldw, 0.f);
     float* W = &blob[F.w_off];
@@ -476,7 +478,7 @@ int launch_nif_f32(pt_handle h, const ptd::NifParams& N) {
       if (l + 1 < n_layers) {
         ptd::NifF32Params G{};
         G.w = h->d_f32_weights + F.w_off; G.bias = h->d_f32_weights + F.b_off;
-        G.ldw = F.ldw; G.k_act = F.k_act; G.k_in = F.k_in; G.relu = F.relu;
+        G.ldw = F.ldw; G.k_act = F.k_act; G.k_in = F.k_in; G.relu = F.relu; G.half_out = F.half_out; G.cast_half = F.cast_half;
         G.act_in = in; G.feat = feat; G.act_out = act[l & 1u];
         G.lda = h->f32_lda; G.ldf = h->f32_ldf;
         G.total_tiles = h->d_tile_start + N.n_regions; G.tile0 = (uint32_t)tile0; G.chunk_tiles = chunk;
@@ -485,7 +487,7 @@ int launch_nif_f32(pt_handle h, const ptd::NifParams& N) {
       } else {
         ptd::NifF32Head Hd{};
         Hd.w = h->d_f32_weights + F.w_off;
-        Hd.k_act = F.k_act; Hd.k_in = F.k_in; Hd.relu = F.relu;
+        Hd.k_act = F.k_act; Hd.k_in = F.k_in; Hd.relu = F.relu; Hd.half_out = F.half_out;
         Hd.bias0 = h->head_bias[0]; Hd.bias1 = h->head_bias[1]; Hd.bias2 = h->head_bias[2];
         Hd.act_in = in; Hd.feat = feat; Hd.lda = h->f32_lda; Hd.ldf = h->f32_ldf;
         Hd.tile0 = (uint32_t)tile0; Hd.chunk_tiles = chunk;

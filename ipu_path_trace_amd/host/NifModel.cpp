@@ -184,14 +184,14 @@ void NifModel::upload(pt_handle device) const {
     p.kernel = l.kernel.data.data();
     p.bias = l.hasBias() ? l.bias.data.data() : nullptr;
     p.relu = l.activationFunction == "relu";
-    // NifModel.cpp:58-60 accepts float16 and float32 layers; the MFMA path computes in fp16, so float32 weights are
-    // rounded to binary16 (RNE) by pt_upload_nif -- a documented deviation
+    // NifModel.cpp:58-60 accepts float16 and float32 layers and gives every matmul its kernel's type (:314): pt_upload_nif
+    // runs each layer in its own type (a model with any float32 layer takes the float path)
     if (l.kernel.type == "float16") p.dtype = PT_DTYPE_F16;
     else if (l.kernel.type == "float32") { p.dtype = PT_DTYPE_F32; converted += 1; }
     else throw std::runtime_error("Unsupported NIF weight type '" + l.kernel.type + "' (expected float16 or float32).");
     ls.push_back(p);
   }
-  if (converted) pt_log::info_("NIF {}: {} float32 layers rounded to float16 for the MFMA path", name, converted);
+  if (converted) pt_log::info_("NIF {}: {} of {} layers are float32: the model runs on the float path (fp32 matrix rate), each layer in its own type", name, converted, ls.size());
   const auto& m = data->getMetaData();
   if (pt_upload_nif(device, ls.data(), (std::uint32_t)ls.size(), (std::uint32_t)m.embeddingDimension, m.max, m.mean.data(),
                     m.logToneMap ? 1 : 0))

@@ -605,6 +605,7 @@ struct orc_nif {
   float max; float mean[3]; int32_t log_tonemap;
   uint32_t max_width;
   int32_t f32;                   /* float32 model: layers run in float (NifModel.cpp:314, kernel type = output type) */
+  int32_t* lf32;                 /* per layer: this layer's variables are float32 (a mixed model; NULL = all layers as `f32`) */
 };
 
 orc_nif* orc_nif_create(const orc_layer* layers, uint32_t n_layers, uint32_t emb, float max,
@@ -653,10 +654,44 @@ orc_nif* orc_nif_create_f32(const orc_layer_f32* layers, uint32_t n_layers, uint
   return m;
 }
 
+/* A model whose layers have their own types: each matmul takes ITS kernel's type (NifModel.cpp:314), the bias add and the
+ * ReLU happen in that type (:316-325), and the activations are cast to the next layer's type where it differs (float ->
+ * half: round to nearest even; half -> float: exact).  The reference states the per-layer type at :314 but ships no mixed
+ * model; the casts between layers are what poplin's "input type = kernel type" needs. */
+orc_nif* orc_nif_create_mixed(const orc_layer_any* layers, uint32_t n_layers, uint32_t emb, float max,
+                              const float mean[3], int32_t log_tonemap) {
+  orc_nif* m = (orc_nif*)calloc(1, sizeof(orc_nif));
+  m->n_layers = n_layers; m->emb = emb; m->max = max; m->log_tonemap = log_tonemap;
+  memcpy(m->mean, mean, 12);
+  m->rows = calloc(n_layers, 4); m->cols = calloc(n_layers, 4);
+  m->relu = calloc(n_layers, 4); m->has_bias = calloc(n_layers, 4); m->lf32 = calloc(n_layers, 4);
+  m->kernel = calloc(n_layers, sizeof(float*)); m->bias = calloc(n_layers, sizeof(float*));
+  m->max_width = 4 * emb;
+  for (uint32_t l = 0; l < n_layers; ++l) {
+    uint32_t r = layers[l].rows, c = layers[l].cols;
+    m->rows[l] = r; m->cols[l] = c; m->relu[l] = layers[l].relu; m->lf32[l] = layers[l].float32 != 0;
+    if (r > m->max_width) m->max_width = r;
+    if (c > m->max_width) m->max_width = c;
+    m->kernel[l] = (float*)malloc((size_t)r * c * 4);
+    m->bias[l] = (float*)calloc(c, 4);
+    m->has_bias[l] = layers[l].bias != NULL;
+    if (m->lf32[l]) {
+      memcpy(m->kernel[l], layers[l].kernel, (size_t)r * c * 4);
+      if (layers[l].bias) memcpy(m->bias[l], layers[l].bias, (size_t)c * 4);
+    } else {
+      const uint16_t* k = (const uint16_t*)layers[l].kernel;
+      const uint16_t* b = (const uint16_t*)layers[l].bias;
+      for (size_t i = 0; i < (size_t)r * c; ++i) m->kernel[l][i] = orc_h2f(k[i]);
+      if (b) for (uint32_t i = 0; i < c; ++i) m->bias[l][i] = orc_h2f(b[i]);
+    }
+  }
+  return m;
+}
+
 void orc_nif_destroy(orc_nif* m) {
   if (!m) return;
   for (uint32_t l = 0; l < m->n_layers; ++l) { free(m->kernel[l]); free(m->bias[l]); }
-  free(m->kernel); free(m->bias); free(m->rows); free(m->cols); free(m->relu); free(m->has_bias);
+  free(m->kernel); free(m->bias); free(m->rows); free(m->cols); free(m->relu); free(m->has_bias); free(m->lf32);
   free(m);
 }
 
@@ -708,7 +743,7 @@ static void nif_layer_fast(const orc_nif* m, uint32_t l, const float* x, float* 
   const uint32_t K = m->rows[l], N = m->cols[l];
   const float* Wt = m->kernel[l];
   const float* bias = m->bias[l];
-  const int f32 = m->f32, has_bias = m->has_bias[l], relu = m->relu[l];
+  const int f32 = m->lf32 ? m->lf32[l] : m->f32, has_bias = m->has_bias[l], relu = m->relu[l];
   uint32_t n0 = 0;
   for (; n0 + 16 <= N; n0 += 16) {
     for (int b0 = 0; b0 < B; b0 += ORC_MB) {
@@ -773,6 +808,7 @@ static void nif_forward(const orc_nif* m, const float* u, const float* v, int B,
   }
   float* x = bufA; float* y = bufB;
   uint32_t xcols = in_dim;
+  int x_is_half = 1;                                    /* the Fourier features are half values */
 #ifndef ORC_FAST_BUILD
   float acc[NIF_BATCH][1024 + 8];
 #endif
@@ -782,6 +818,10 @@ static void nif_forward(const orc_nif* m, const float* u, const float* v, int B,
       for (int b = 0; b < B; ++b) memcpy(x + (size_t)b * W + xcols, input + (size_t)b * in_dim, in_dim * 4);
       xcols += in_dim;
     }
+    const int lf32 = m->lf32 ? m->lf32[l] : m->f32;
+    if (!lf32 && !x_is_half)                            /* a float16 layer behind a float32 one: its input is cast to half */
+      for (int b = 0; b < B; ++b) for (uint32_t k = 0; k < xcols; ++k) x[(size_t)b * W + k] = hround(x[(size_t)b * W + k]);
+    x_is_half = !lf32;
 #ifdef ORC_FAST_BUILD
     nif_layer_fast(m, l, x, y, B, W);
 #else
@@ -798,8 +838,8 @@ static void nif_forward(const orc_nif* m, const float* u, const float* v, int B,
         }
       }
       for (int b = 0; b < B; ++b) for (uint32_t n = 0; n < nn; ++n) {
-        float o = m->f32 ? acc[b][n] : hround(acc[b][n]);   /* matmul output type = kernel type (:314) */
-        if (m->has_bias[l]) o = m->f32 ? o + m->bias[l][n0 + n] : hround(o + m->bias[l][n0 + n]);   /* addInPlace :316-321 */
+        float o = lf32 ? acc[b][n] : hround(acc[b][n]);   /* matmul output type = kernel type (:314) */
+        if (m->has_bias[l]) o = lf32 ? o + m->bias[l][n0 + n] : hround(o + m->bias[l][n0 + n]);   /* addInPlace :316-321 */
         if (m->relu[l] && !(o > 0.f)) o = 0.f;          /* ReLU :323-325 */
         y[(size_t)b * W + n0 + n] = o;
       }

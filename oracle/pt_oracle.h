@@ -76,6 +76,15 @@ typedef struct {
   int32_t relu;
 } orc_layer_f32;
 
+/* A layer of either type, for models that mix them (float32 != 0: kernel and bias are float, else binary16 bits). */
+typedef struct {
+  uint32_t rows, cols;
+  const void* kernel;
+  const void* bias;
+  int32_t relu;
+  int32_t float32;
+} orc_layer_any;
+
 typedef struct orc_nif orc_nif;
 
 typedef struct {
@@ -98,6 +107,8 @@ orc_nif* orc_nif_create(const orc_layer* layers, uint32_t n_layers, uint32_t emb
                         float max, const float mean_folded[3], int32_t log_tonemap);
 orc_nif* orc_nif_create_f32(const orc_layer_f32* layers, uint32_t n_layers, uint32_t embedding_dim,
                             float max, const float mean[3], int32_t log_tonemap);
+orc_nif* orc_nif_create_mixed(const orc_layer_any* layers, uint32_t n_layers, uint32_t embedding_dim,
+                              float max, const float mean[3], int32_t log_tonemap);
 void orc_nif_destroy(orc_nif*);
 /* u,v -> bgr (decoded).  Also the streamed-IO standalone mode of NifModel.cpp:268-278. */
 int orc_nif_infer(const orc_nif*, const float* u, const float* v, size_t n, float* bgr);

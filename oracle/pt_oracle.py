@@ -81,6 +81,11 @@ class Layer(C.Structure):
                 ("relu", C.c_int32)]
 
 
+class LayerAny(C.Structure):
+    _fields_ = [("rows", C.c_uint32), ("cols", C.c_uint32), ("kernel", C.c_void_p), ("bias", C.c_void_p),
+                ("relu", C.c_int32), ("float32", C.c_int32)]
+
+
 class Path(C.Structure):
     _fields_ = [("length", C.c_uint32), ("escaped", C.c_uint32), ("dir", C.c_float * 3), ("uv", C.c_float * 2),
                 ("throughput", C.c_float * 3), ("cam", C.c_float * 2)]
@@ -121,6 +126,8 @@ def _bind(L):
         L.orc_nif_create.argtypes = [C.POINTER(Layer), C.c_uint32, C.c_uint32, C.c_float, fp, C.c_int32]
         L.orc_nif_create_f32.restype = C.c_void_p
         L.orc_nif_create_f32.argtypes = [C.POINTER(Layer), C.c_uint32, C.c_uint32, C.c_float, fp, C.c_int32]
+        L.orc_nif_create_mixed.restype = C.c_void_p
+        L.orc_nif_create_mixed.argtypes = [C.POINTER(LayerAny), C.c_uint32, C.c_uint32, C.c_float, fp, C.c_int32]
         L.orc_nif_destroy.argtypes = [C.c_void_p]
         L.orc_nif_infer.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.orc_nif_encode.argtypes = [C.c_uint32, C.c_float, C.c_float, C.c_void_p]
@@ -184,17 +191,19 @@ def make_config(width=256, height=256, max_path_length=10, roulette_depth=3, sto
 
 
 class Nif:
-    """Owns an orc_nif built from (kernel [in,out], bias [out] | None, relu) triples.  A model ALL of whose kernels are
-    float32 runs in float (the reference gives a matmul its kernel's type, NifModel.cpp:314); anything else is a float16
-    model (float32 entries are rounded to binary16, as the device library does for a float32 layer inside a float16 model)."""
+    """Owns an orc_nif built from (kernel [in,out], bias [out] | None, relu) triples.  Every layer runs in the type of its own
+    kernel (the reference gives a matmul its kernel's type, NifModel.cpp:314): a float32 kernel -> that layer in float, anything
+    else -> binary16, with the activations cast between layers of different types (orc_nif_create_mixed)."""
 
     def __init__(self, layers, embedding_dim, max_value, mean_folded, log_tonemap=True, fast=False):
         self._keep = []
         self._lib = lib(fast)
-        arr = (Layer * len(layers))()
-        self.float32 = all(np.asarray(k).dtype == np.float32 for k, _, _ in layers)
-        dt = np.float32 if self.float32 else np.float16
+        arr = (LayerAny * len(layers))()
+        kinds = [np.asarray(k).dtype == np.float32 for k, _, _ in layers]
+        self.float32 = all(kinds)
+        self.mixed = any(kinds) and not all(kinds)
         for i, (k, b, relu) in enumerate(layers):
+            dt = np.float32 if kinds[i] else np.float16
             k = np.ascontiguousarray(k, dtype=dt)
             self._keep.append(k)
             arr[i].rows, arr[i].cols = k.shape
@@ -204,9 +213,9 @@ class Nif:
                 self._keep.append(b)
                 arr[i].bias = b.ctypes.data
             arr[i].relu = int(bool(relu))
+            arr[i].float32 = int(kinds[i])
         mean = (C.c_float * 3)(*[float(x) for x in mean_folded])
-        create = self._lib.orc_nif_create_f32 if self.float32 else self._lib.orc_nif_create
-        self.handle = create(arr, len(layers), embedding_dim, float(max_value), mean, int(log_tonemap))
+        self.handle = self._lib.orc_nif_create_mixed(arr, len(layers), embedding_dim, float(max_value), mean, int(log_tonemap))
         self.embedding_dim = embedding_dim
 
     def __del__(self):

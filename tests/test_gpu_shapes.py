@@ -125,10 +125,12 @@ def test_float32_model_spans_chunks(oracle, ptmi_lib):
     assert np.isfinite(got).all() and rel.max() < NIF_RTOL_MAX and np.median(rel) < 2e-5, (rel.max(), np.median(rel))
 
 
-def test_float32_model_renders_and_a_mixed_model_is_rounded(oracle, ptmi_lib):
+def test_float32_model_renders_and_a_mixed_model_runs_each_layer_in_its_type(oracle, ptmi_lib):
     """The float path inside the whole step (queue, chunks, scatter, accumulate) against the oracle's float mode; and a
-    float32 layer inside a float16 model is rounded to binary16 on upload (documented in include/ptmi.h): bit-identical
-    to uploading the rounded weights."""
+    model that MIXES float32 and float16 layers runs every layer in the type of its own kernel (NifModel.cpp:314: a matmul
+    takes its kernel's type): the float16 layers round their sums to half, add their bias in half and read their input cast
+    to half, the float32 layers do none of that -- against the oracle's mixed mode (orc_nif_create_mixed), for every
+    placement of the float32 layers, the head included."""
     O = oracle
     W = H = 48
     L32 = nif_assets.synthetic_nif(hidden=64, layer_count=3, seed=8, dtype=np.float32)
@@ -147,15 +149,28 @@ def test_float32_model_renders_and_a_mixed_model_is_rounded(oracle, ptmi_lib):
     assert st.nif_flops_per_sample == nif_assets.flops_per_sample(L32)
     for c in "rgb":
         np.testing.assert_allclose(rec[c], ref[c], rtol=NIF_RTOL_MAX, atol=1e-6)
-    mixed = [(k.astype(np.float16), b.astype(np.float16), relu) if i == 1 else (k, b, relu) for i, (k, b, relu) in enumerate(L32)]
+
     L16 = [(k.astype(np.float16), b.astype(np.float16), relu) for k, b, relu in L32]
-    u = np.linspace(0.01, 0.99, 300, dtype=np.float32)
-    r.init_nif_weights(mixed, 12, META["max"], mean)
-    a = r.nif_infer(u, u[::-1].copy())
+    rng = np.random.default_rng(9)
+    u, v = rng.random(3000, dtype=np.float32), rng.random(3000, dtype=np.float32)
     r.init_nif_weights(L16, 12, META["max"], mean)
-    b = r.nif_infer(u, u[::-1].copy())
+    all_half = r.nif_infer(u, v)
+    n = len(L32)
+    for f32_layers in ([1], [0], [n - 1], [0, n - 1], [1, 2], list(range(n - 1))):   # which layers keep float32 variables
+        mixed = [L32[i] if i in f32_layers else L16[i] for i in range(n)]
+        onif = O.Nif(mixed, 12, META["max"], mean)
+        assert onif.mixed and not onif.float32
+        r.init_nif_weights(mixed, 12, META["max"], mean)
+        assert "nif32_layer_kernel" in (r.nif_infer(u[:1], v[:1]), r.nif_kernel_name())[1]   # a mixed model takes the float path
+        got, want = r.nif_infer(u, v), onif.infer(u, v)
+        assert np.isfinite(got).all()
+        rel = np.abs(got - want) / np.abs(want)
+        # every layer is the same k-ordered fp32 FMA chain on both sides; what differs is the half-precision trig of the
+        # features (v_sin against libm), which a half rounding downstream can amplify to one half-ulp of a hidden activation
+        assert rel.max() < NIF_RTOL_MAX and np.median(rel) < 2e-4, (f32_layers, rel.max(), np.median(rel))
+        # ... and it is NOT the all-float16 result (what rounds 1-3 computed for such a model)
+        assert np.median(np.abs(got - all_half) / np.abs(all_half)) > 2e-5, f32_layers
     r.close()
-    assert a.tobytes() == b.tobytes()
 
 
 def test_shapes_the_reference_would_reject(ptmi_lib):

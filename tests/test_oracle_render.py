@@ -177,3 +177,40 @@ def test_nif_float32_mode_against_numpy(oracle):
     half = oracle.Nif([(k.astype(np.float16), b.astype(np.float16), r) for k, b, r in L], 10, meta["max"], nif_assets.folded_mean())
     assert not half.float32
     assert np.median(np.abs(half.infer(u, v) - out) / out) > 1e-4
+
+
+@pytest.mark.parametrize("f32_layers", [[1], [0, 3], [3], [0, 1, 2]])
+def test_nif_mixed_mode_against_numpy(oracle, f32_layers):
+    """A model that mixes float32 and float16 layers: every matmul takes ITS kernel's type (NifModel.cpp:314), the bias add and
+    ReLU happen in that type (:316-325), activations are cast to the next layer's type.  The oracle's mixed mode against an
+    independent numpy restatement (float64 products, the rounding points placed by hand)."""
+    L32 = nif_assets.synthetic_nif(hidden=96, layer_count=4, embedding_dim=10, seed=4, dtype=np.float32)
+    L16 = [(k.astype(np.float16), b.astype(np.float16), r) for k, b, r in L32]
+    mixed = [L32[i] if i in f32_layers else L16[i] for i in range(len(L32))]
+    meta = nif_assets.URBAN_ALLEY_META
+    nif = oracle.Nif(mixed, 10, meta["max"], nif_assets.folded_mean())
+    assert nif.mixed and nif.flops_per_sample() == nif_assets.flops_per_sample(L32)
+    rng = np.random.default_rng(2)
+    u, v = rng.random(200, dtype=np.float32), rng.random(200, dtype=np.float32)
+    out = nif.infer(u, v)
+    f = np.stack([oracle.nif_encode(10, a, b) for a, b in zip(u, v)]).astype(np.float64)   # half values
+    x = f.copy()
+    for i, (k, b, relu) in enumerate(mixed):
+        if x.shape[1] != k.shape[0]:
+            x = np.concatenate([x, f], 1)
+        if i in f32_layers:
+            x = x @ k.astype(np.float64) + b.astype(np.float64)
+        else:
+            x = x.astype(np.float32).astype(np.float16).astype(np.float64)                  # input cast to the matmul's type
+            y = (x @ k.astype(np.float64)).astype(np.float32).astype(np.float16)           # output type = kernel type
+            x = (y + b).astype(np.float16).astype(np.float64)                               # bias add in half
+        if relu:
+            x = np.maximum(x, 0.0)
+    ref = np.exp(x[:, :3] * meta["max"] + np.asarray(nif_assets.folded_mean(), dtype=np.float64))
+    # float64 products against the oracle's fp32 FMA chain: a half rounding downstream can move a hidden activation by one
+    # half-ulp on a few samples, hence the same tolerance as the float16 test above
+    np.testing.assert_allclose(out, ref, rtol=5e-3)
+    assert np.median(np.abs(out - ref) / ref) < 5e-5
+    for other in (L32, L16):                                                                 # neither pure mode's answer
+        pure = oracle.Nif(other, 10, meta["max"], nif_assets.folded_mean()).infer(u, v)
+        assert np.median(np.abs(pure - out) / out) > 1e-5
