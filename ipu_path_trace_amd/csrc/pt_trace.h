@@ -40,6 +40,11 @@ struct SceneObject {
   float colr, colg, colb;
   int32_t type;         // MAT_*
   int32_t is_disc;
+  // Camera rays start at the origin (codelets.cpp:162): what Sphere / Disc::intersect compute from (origin, object) alone
+  // is a constant of the object, formed on the host by the SAME binary32 expressions in the same order (fill_scene):
+  float ocx, ocy, ocz;  // sub(o, c) at o = 0
+  float c4;             // 4.0f * (dot(oc, oc) - r2)
+  float kdisc;          // dot(sub(c, o), n) at o = 0 (disc)
 };
 
 struct TraceParams {
@@ -68,7 +73,22 @@ struct TraceParams {
   uint4* survivors;          // [gridDim.x][region_cap] primary-phase notes: path index, camera ray (two halves), hit distance, object
   float4* states;            // [3][gridDim.x][region_cap] path states after the first shading: (o, d.x), (d.yz, T.xy), (T.z, idx)
   size_t state_stride;       // gridDim.x * region_cap
+  uint32_t div_magic, div_shift;   // idx / n_items = (idx * div_magic) >> div_shift, exact for idx < 2^31 (ptmi_context.h: item_divider)
+  unsigned long long* diag;        // profiling build: secondary-phase occupancy counters (OPT bit 4), else nullptr
 };
+
+// path index -> (work item, sample iteration).  A 32-bit division costs ~25 vector instructions on this chip and every path
+// needs one (survivors two more); n_items is fixed per launch, so the host supplies the round-up reciprocal.
+template <bool MAGIC>
+__device__ __forceinline__ void split_index(const TraceParams& P, uint32_t idx, uint32_t& item, uint32_t& iter) {
+  if constexpr (MAGIC) {
+    iter = (uint32_t)(((uint64_t)idx * P.div_magic) >> P.div_shift);
+    item = idx - iter * P.n_items;
+  } else {
+    iter = idx / P.n_items;
+    item = idx % P.n_items;
+  }
+}
 
 struct PathState {
   Vec3 o, d, T;
@@ -166,6 +186,43 @@ __device__ __forceinline__ int nearest_hit(const TraceParams& P, Vec3 o, Vec3 d,
   for (int i = 0; i < kNumObjects; ++i) {
     const SceneObject ob = P.obj[i];
     float t = ob.is_disc ? disc_intersect(o, d, ob) : sphere_intersect(o, d, ob);
+    if (t > kEps && t < tbest) { tbest = t; best = i; }
+  }
+  return best;
+}
+
+// The same for a camera ray (origin exactly 0): sub(o, c), dot(oc, oc) - r2 and dot(sub(c, o), n) are the object's host-made
+// constants, everything that depends on the direction is the expression of sphere_intersect / disc_intersect unchanged, so
+// the result is the same float.  (Disc: the hit point add(o, scale(d, t)) is scale(d, t) but for the sign of a zero, which
+// sub(p, c) and the squares that follow erase.)
+__device__ __forceinline__ int nearest_hit_primary(const TraceParams& P, Vec3 d, float& tbest) {
+  int best = -1;
+  tbest = kInf;
+#pragma unroll 1
+  for (int i = 0; i < kNumObjects; ++i) {
+    const SceneObject ob = P.obj[i];
+    float t;
+    if (ob.is_disc) {
+      const Vec3 n = mk(ob.nx, ob.ny, ob.nz), c = mk(ob.cx, ob.cy, ob.cz);
+      const float denom = dot(n, d);
+      t = 0.0f;
+      if (denom != 0.0f) {
+        const float tt = ob.kdisc / denom;
+        if (tt > kEps) {
+          const Vec3 pc = sub(scale(d, tt), c);
+          if (!(dot(pc, pc) > ob.r2)) t = tt;
+        }
+      }
+    } else {
+      const float b = 2.0f * dot(mk(ob.ocx, ob.ocy, ob.ocz), d);
+      float disc = b * b - ob.c4;
+      t = 0.0f;
+      if (!(disc < 0.0f)) {
+        disc = sqrtf(disc);
+        const float sol1 = -b + disc, sol2 = -b - disc;
+        t = (sol2 > kEps) ? sol2 * 0.5f : ((sol1 > kEps) ? sol1 * 0.5f : 0.0f);
+      }
+    }
     if (t > kEps && t < tbest) { tbest = t; best = i; }
   }
   return best;
@@ -335,8 +392,23 @@ __device__ __forceinline__ uint32_t pack_half2(float a, float b) {   // both are
   return c.u;
 }
 
-template <uint32_t REFILL>
+#ifdef PTMI_DIAG_BUILD
+}  // namespace ptd
+#include "diag/pt_trace_rounds.h"   // round-4 experiment: the secondary phase in workgroup-synchronous, material-sorted rounds (not kept)
+namespace ptd {
+#endif
+
+// OPT (round 4; the product has both, the profiling build keeps the others for the A/B): bit 0 = path index split by a
+// reciprocal multiply instead of a division, bit 1 = the camera ray's intersection with the origin folded into constants.
+// Profiling build only: bits 2 / 3 timing-only phase cuts, bit 4 occupancy counters of the secondary loop, bit 5 the
+// secondary phase in workgroup-synchronous rounds that regroup the paths by material (diag/pt_trace_rounds.h): 14 % fewer
+// instructions and 78.7 % lane utilisation, but no faster on its own (the VALU goes from 97 % to 84 % busy behind two
+// workgroup barriers per 256 paths) and 2 % slower inside the C2 step -- its 16 KiB of LDS do not fit beside the NIF
+// kernel's 157 KiB, so the trace kernel loses its place under the MFMA kernel (profiles/r04_trace_ablation.txt).
+constexpr int kTraceOpt = 3;
+template <uint32_t REFILL, int OPT = kTraceOpt>
 __device__ __forceinline__ void trace_body(const TraceParams& P) {
+  constexpr bool MAGIC = (OPT & 1) != 0, PRIMARY = (OPT & 2) != 0;
   __shared__ uint32_t wg_count;   // escaped paths queued by this workgroup
   __shared__ uint32_t wg_front, wg_back;   // camera rays of this workgroup that hit a diffuse / a mirror or glass object
   __shared__ uint32_t wg_state;            // survivors still alive after their first shading
@@ -364,8 +436,10 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
     float camx = 0.f, camy = 0.f, tbest = 0.f;
     int best = -1;
     if (valid) {
-      start_path(P, P.pix[idx % P.n_items], P.sample_base + idx / P.n_items, st, camx, camy);
-      best = nearest_hit(P, st.o, st.d, tbest);
+      uint32_t item, iter;
+      split_index<MAGIC>(P, idx, item, iter);
+      start_path(P, P.pix[item], P.sample_base + iter, st, camx, camy);
+      best = PRIMARY ? nearest_hit_primary(P, st.d, tbest) : nearest_hit(P, st.o, st.d, tbest);
     }
     const bool hit = best >= 0;
     // a miss at depth 0 is final (codelets.cpp:184-190): one record, no roulette below roulette_depth >= 1, so the
@@ -393,7 +467,7 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
     if (hit) surv[pos] = make_uint4(idx, pack_half2(camx, camy), __float_as_uint(tbest), (uint32_t)best);
   }
   __syncthreads();   // the workgroup's survivor list is complete (and visible: the workgroup's own global stores, first read now)
-  const uint32_t n_front = wg_front, n_surv = n_front + wg_back;
+  const uint32_t n_front = wg_front, n_surv = (OPT & 8) ? 0u : n_front + wg_back;   // (bit 3, timing only: primary phase alone)
 
   // ---- first-shading phase: survivor v of the list (front part, then back part) gets its depth-0 bounce finished -- the half
   // of a loop trip behind the intersection -- 64 survivors per wave and trip, a chunk inside the front part all diffuse
@@ -411,8 +485,10 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
       st.o = mk(0.f, 0.f, 0.f);
       st.d = normalise(mk((float)cam.h[0], (float)cam.h[1], -1.f));      // as start_path (codelets.cpp:162-163)
       st.T = mk(1.f, 1.f, 1.f);
-      st.pixel = P.pix[idx % P.n_items];
-      st.sample = P.sample_base + idx / P.n_items;
+      uint32_t item, iter;
+      split_index<MAGIC>(P, idx, item, iter);
+      st.pixel = P.pix[item];
+      st.sample = P.sample_base + iter;
       st.depth = 0;
       uint32_t w[4];
       philox4x32_10(st.pixel, st.sample, 1u, 0x5054u, P.seed_lo, P.seed_hi, w);   // the block of bounce 0; no roulette at depth 0
@@ -435,9 +511,17 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
     }
   }
   __syncthreads();
-  const uint32_t n_state = wg_state;
+  const uint32_t n_state = (OPT & 4) ? 0u : wg_state;   // (bit 2, timing only: no secondary phase)
 
-  // ---- secondary phase: the path loop over the shaded survivors, persistent lanes.  Wave w owns entries
+#ifdef PTMI_DIAG_BUILD
+  if constexpr ((OPT & 32) != 0) {
+    secondary_rounds(P, hit_table, n_state, st0, st1, st2, region_base, &wg_count);
+    __syncthreads();
+    if (threadIdx.x == 0) P.region_count[blockIdx.x] = wg_count;
+    return;
+  }
+#endif
+  // ---- secondary phase (round 3, profiling build): the path loop over the shaded survivors, persistent lanes.  Wave w owns entries
   // e(j) = ((j / 64) * 4 + w) * 64 + j % 64 of the state list; an idle lane takes the next one and goes on at depth 1.
   uint32_t cursor = 0;
   const uint32_t s_chunks = (n_state + 63u) / 64u;
@@ -445,6 +529,7 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
   PathState st;
   uint32_t idx = 0;
   bool active = false;
+  uint32_t dg_trips = 0, dg_active = 0, dg_tail_trips = 0, dg_tail_active = 0;   // (OPT bit 4 only)
   while (true) {
     const uint64_t act_mask = __ballot(active);
     const uint32_t n_active = (uint32_t)__popcll(act_mask);
@@ -462,13 +547,20 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
           st.d = mk(a.w, b.x, b.y);
           st.T = mk(b.z, b.w, c.x);
           idx = __float_as_uint(c.y);
-          st.pixel = P.pix[idx % P.n_items];
-          st.sample = P.sample_base + idx / P.n_items;
+          uint32_t item, iter;
+          split_index<MAGIC>(P, idx, item, iter);
+          st.pixel = P.pix[item];
+          st.sample = P.sample_base + iter;
           st.depth = 1;
           active = true;
         }
       }
       cursor += 64u - n_active;
+    }
+    if constexpr ((OPT & 16) != 0) {
+      const uint32_t na = (uint32_t)__popcll(__ballot(active));
+      dg_trips += 1; dg_active += na;
+      if (cursor >= mine) { dg_tail_trips += 1; dg_tail_active += na; }
     }
     int res = STEP_CONTINUE;
     uint32_t length = 0;
@@ -481,6 +573,12 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
     }
     emit_escaped(P, escaped, st, idx, lane, region_base, &wg_count);
   }
+  if constexpr ((OPT & 16) != 0) {
+    if (lane == 0 && P.diag) {
+      atomicAdd(&P.diag[0], (unsigned long long)dg_trips); atomicAdd(&P.diag[1], (unsigned long long)dg_active);
+      atomicAdd(&P.diag[2], (unsigned long long)dg_tail_trips); atomicAdd(&P.diag[3], (unsigned long long)dg_tail_active);
+    }
+  }
   __syncthreads();
   if (threadIdx.x == 0) P.region_count[blockIdx.x] = wg_count;
 }
@@ -489,6 +587,8 @@ __global__ __launch_bounds__(kTraceBlock) void trace_kernel(const TraceParams P)
 #ifdef PTMI_DIAG_BUILD
 template <uint32_t REFILL>
 __global__ __launch_bounds__(kTraceBlock) void trace_kernel_refill(const TraceParams P) { trace_body<REFILL>(P); }   // threshold sweep
+template <int OPT>
+__global__ __launch_bounds__(kTraceBlock) void trace_kernel_opt(const TraceParams P) { trace_body<kRefillThreshold, OPT>(P); }   // round-4 A/B (0 = the round-3 kernel; 7, 11: timing-only phase cuts)
 #endif
 
 struct PathRecordOut {  // layout of pt_path_record (include/ptmi.h)

@@ -463,6 +463,24 @@ static int enqueue_path_trace(pt_handle h, std::vector<StageSpan>& spans, size_t
       hipLaunchKernelGGL(ptd::trace_kernel_refill<16>, dim3(g.blocks), dim3(ptd::kTraceBlock), 0, h->trace_stream, P);
     else if (tk && !strcmp(tk, "r24"))
       hipLaunchKernelGGL(ptd::trace_kernel_refill<24>, dim3(g.blocks), dim3(ptd::kTraceBlock), 0, h->trace_stream, P);
+    else if (tk && !strcmp(tk, "opt0"))   // the round-3 kernel: neither round-4 change
+      hipLaunchKernelGGL(ptd::trace_kernel_opt<0>, dim3(g.blocks), dim3(ptd::kTraceBlock), 0, h->trace_stream, P);
+    else if (tk && !strcmp(tk, "opt1"))
+      hipLaunchKernelGGL(ptd::trace_kernel_opt<1>, dim3(g.blocks), dim3(ptd::kTraceBlock), 0, h->trace_stream, P);
+    else if (tk && !strcmp(tk, "opt2"))
+      hipLaunchKernelGGL(ptd::trace_kernel_opt<2>, dim3(g.blocks), dim3(ptd::kTraceBlock), 0, h->trace_stream, P);
+    else if (tk && !strcmp(tk, "rounds"))   // the secondary phase in workgroup-synchronous, material-sorted rounds (diag/pt_trace_rounds.h)
+      hipLaunchKernelGGL(ptd::trace_kernel_opt<35>, dim3(g.blocks), dim3(ptd::kTraceBlock), 0, h->trace_stream, P);
+    else if (tk && !strcmp(tk, "count")) {   // secondary-phase occupancy counters into the stamp buffer (pt_diag_stamps)
+      if (!h->d_stamps) { PT_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_stamps), 256 * 8)); PT_HIP(hipMemset(h->d_stamps, 0, 256 * 8)); }
+      ptd::TraceParams PC = P;
+      PC.diag = h->d_stamps;
+      hipLaunchKernelGGL(ptd::trace_kernel_opt<19>, dim3(g.blocks), dim3(ptd::kTraceBlock), 0, h->trace_stream, PC);
+    }
+    else if (tk && !strcmp(tk, "cut2"))   // timing only: no secondary phase
+      hipLaunchKernelGGL(ptd::trace_kernel_opt<7>, dim3(g.blocks), dim3(ptd::kTraceBlock), 0, h->trace_stream, P);
+    else if (tk && !strcmp(tk, "cut1"))   // timing only: primary phase alone
+      hipLaunchKernelGGL(ptd::trace_kernel_opt<11>, dim3(g.blocks), dim3(ptd::kTraceBlock), 0, h->trace_stream, P);
     else
 #endif
     hipLaunchKernelGGL(ptd::trace_kernel, dim3(g.blocks), dim3(ptd::kTraceBlock), 0, h->trace_stream, P);

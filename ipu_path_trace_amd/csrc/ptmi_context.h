@@ -211,7 +211,29 @@ void fill_scene(ptd::TraceParams& P) {
     o.colr = src[i].col[0]; o.colg = src[i].col[1]; o.colb = src[i].col[2];
     o.type = src[i].type;
     o.is_disc = src[i].disc;
+    // constants of a ray that starts at the origin, by the device's own expressions (this file is compiled with
+    // -ffp-contract=off like the kernels; volatile keeps every intermediate a rounded binary32 whatever the host's FLT_EVAL_METHOD)
+    volatile float ox = 0.f - o.cx, oy = 0.f - o.cy, oz = 0.f - o.cz;          // sub(o, c)
+    volatile float xx = ox * ox, yy = oy * oy, zz = oz * oz;
+    volatile float d0 = xx + yy, d1 = d0 + zz;                                 // dot(oc, oc), left to right
+    volatile float cc = d1 - o.r2;
+    o.ocx = ox; o.ocy = oy; o.ocz = oz;
+    o.c4 = 4.0f * cc;
+    volatile float kx = (o.cx - 0.f) * o.nx, ky = (o.cy - 0.f) * o.ny, kz = (o.cz - 0.f) * o.nz;   // dot(sub(c, o), n)
+    volatile float k0 = kx + ky, k1 = k0 + kz;
+    o.kdisc = k1;
   }
+}
+
+// Round-up reciprocal of the work-item count: (x * magic) >> shift == x / n for every x < 2^31 (Granlund & Montgomery: with
+// s = ceil(log2 n) and magic = floor(2^(31+s) / n) + 1 the error magic * n - 2^(31+s) lies in (0, 2^s], so the product's excess
+// over x / n stays below 1 / n).  The batch size keeps path indices below 2^31 (pt_create).
+void item_divider(uint32_t n, uint32_t& magic, uint32_t& shift) {
+  uint32_t s = 0;
+  while ((1ull << s) < n) ++s;
+  const uint64_t m = ((1ull << (31 + s)) / n) + 1ull;
+  magic = (uint32_t)m;     // < 2^32: n > 2^(s-1)
+  shift = 31 + s;
 }
 
 void fill_trace_params(pt_handle h, ptd::TraceParams& P) {
@@ -239,6 +261,7 @@ void fill_trace_params(pt_handle h, ptd::TraceParams& P) {
   P.env_r = h->env_rgb[0]; P.env_g = h->env_rgb[1]; P.env_b = h->env_rgb[2];
   P.pix = h->acc.pix;
   P.state_stride = h->queue_cap;
+  item_divider(h->n_items ? h->n_items : 1u, P.div_magic, P.div_shift);
 }
 
 void bind_batch(ptd::TraceParams& P, const pt_context::BatchBuffers& B) {
