@@ -45,6 +45,7 @@ struct SceneObject {
   float ocx, ocy, ocz;  // sub(o, c) at o = 0
   float c4;             // 4.0f * (dot(oc, oc) - r2)
   float kdisc;          // dot(sub(c, o), n) at o = 0 (disc)
+  int32_t same_centre;  // a sphere whose centre equals that of the sphere declared just before it
 };
 
 struct TraceParams {
@@ -179,13 +180,33 @@ __device__ __forceinline__ float disc_intersect(Vec3 o, Vec3 d, const SceneObjec
 // Scene::intersect (codelets.cpp:183): nearest hit in declaration order, -1 for none.
 // The loop stays rolled: one object's constants at a time are fetched from the kernel-argument segment (scalar
 // loads, wave-uniform), instead of all of them living in SGPRs.
+// A sphere that shares its centre with the object declared before it (the clear-coat pair, codelets.cpp:115-116) reuses that
+// object's sub(o, c), dot(oc, d) and dot(oc, oc): the same expressions on the same values (wave-uniform flag from the host).
 __device__ __forceinline__ int nearest_hit(const TraceParams& P, Vec3 o, Vec3 d, float& tbest) {
   int best = -1;
   tbest = kInf;
+  float b = 0.f, oc2 = 0.f;
 #pragma unroll 1
   for (int i = 0; i < kNumObjects; ++i) {
     const SceneObject ob = P.obj[i];
-    float t = ob.is_disc ? disc_intersect(o, d, ob) : sphere_intersect(o, d, ob);
+    float t;
+    if (ob.is_disc) {
+      t = disc_intersect(o, d, ob);
+    } else {
+      if (!ob.same_centre) {
+        const Vec3 oc = sub(o, mk(ob.cx, ob.cy, ob.cz));
+        b = 2.0f * dot(oc, d);
+        oc2 = dot(oc, oc);
+      }
+      const float c_ = oc2 - ob.r2;                       // sphere_intersect from here on
+      float disc = b * b - 4.0f * c_;
+      t = 0.0f;
+      if (!(disc < 0.0f)) {   // (a real branch on purpose: a wave none of whose rays comes near the sphere skips the rest)
+        disc = sqrtf(disc);
+        const float sol1 = -b + disc, sol2 = -b - disc;
+        t = (sol2 > kEps) ? sol2 * 0.5f : ((sol1 > kEps) ? sol1 * 0.5f : 0.0f);
+      }
+    }
     if (t > kEps && t < tbest) { tbest = t; best = i; }
   }
   return best;
@@ -198,6 +219,7 @@ __device__ __forceinline__ int nearest_hit(const TraceParams& P, Vec3 o, Vec3 d,
 __device__ __forceinline__ int nearest_hit_primary(const TraceParams& P, Vec3 d, float& tbest) {
   int best = -1;
   tbest = kInf;
+  float b = 0.f;
 #pragma unroll 1
   for (int i = 0; i < kNumObjects; ++i) {
     const SceneObject ob = P.obj[i];
@@ -214,7 +236,7 @@ __device__ __forceinline__ int nearest_hit_primary(const TraceParams& P, Vec3 d,
         }
       }
     } else {
-      const float b = 2.0f * dot(mk(ob.ocx, ob.ocy, ob.ocz), d);
+      if (!ob.same_centre) b = 2.0f * dot(mk(ob.ocx, ob.ocy, ob.ocz), d);
       float disc = b * b - ob.c4;
       t = 0.0f;
       if (!(disc < 0.0f)) {
@@ -256,6 +278,14 @@ __device__ __forceinline__ int shade_hit(const TraceParams& P, const HitRow* tab
 // AccumulateContributions fold (codelets.cpp:255-292) carried forward as throughput T.
 // Returns the path length (contribution-stack size, codelets.cpp:253) through `length` when the
 // path ends.
+template <bool LEGACY = false>
+__device__ __forceinline__ int bounce(const TraceParams& P, const HitRow* tab, PathState& s, uint32_t& length);
+#ifdef PTMI_DIAG_BUILD
+__device__ __forceinline__ int nearest_hit_r3(const TraceParams& P, Vec3 o, Vec3 d, float& tbest);
+__device__ __forceinline__ int shade_hit_r3(const TraceParams& P, const HitRow* tab, PathState& s, int best, float tbest,
+                                            const uint32_t (&w)[4], float rr, uint32_t& length);
+#endif
+template <bool LEGACY>
 __device__ __forceinline__ int bounce(const TraceParams& P, const HitRow* tab, PathState& s, uint32_t& length) {
   uint32_t w[4];
   philox4x32_10(s.pixel, s.sample, 1u + s.depth, 0x5054u, P.seed_lo, P.seed_hi, w);
@@ -269,12 +299,20 @@ __device__ __forceinline__ int bounce(const TraceParams& P, const HitRow* tab, P
     rr = P.rr_factor;
   }
   float tbest;
-  const int best = nearest_hit(P, s.o, s.d, tbest);           // Scene::intersect (:183)
+  int best;
+#ifdef PTMI_DIAG_BUILD
+  if constexpr (LEGACY) best = nearest_hit_r3(P, s.o, s.d, tbest);
+  else
+#endif
+  best = nearest_hit(P, s.o, s.d, tbest);                     // Scene::intersect (:183)
   if (best < 0) {                                             // :184-190 ESCAPED
     s.T = scale(s.T, rr);
     length = s.depth + 1u;
     return STEP_ESCAPED;
   }
+#ifdef PTMI_DIAG_BUILD
+  if constexpr (LEGACY) return shade_hit_r3(P, tab, s, best, tbest, w, rr, length);
+#endif
   return shade_hit(P, tab, s, best, tbest, w, rr, length);
 }
 
@@ -309,30 +347,37 @@ __device__ __forceinline__ int shade_hit(const TraceParams& P, const HitRow* tab
     s.d = mk(dot(mk(rx.x, ry.x, n.x), h), dot(mk(rx.y, ry.y, n.y), h), dot(mk(rx.z, ry.z, n.z), h));
     float cost = dot(s.d, n);
     s.T = scale(cwise(s.T, mk(cr, cg, cb)), cost * rr);
-  } else if (type == MAT_SPECULAR) {                          // :205-207, light::reflect
-    float cost = dot(s.d, n);
-    s.d = normalise(sub(s.d, scale(n, cost * 2.0f)));
-    s.T = scale(s.T, rr);
-  } else {                                                    // :208-213, light::refract
-    float u = uniform01(w[1], P.samples_half);
-    float nn = P.ri;
-    float r0 = (1.0f - nn) / (1.0f + nn);
-    r0 = r0 * r0;
-    if (dot(n, s.d) > 0.0f) { n = scale(n, -1.0f); nn = 1.0f / nn; }
-    nn = 1.0f / nn;
-    float cost1 = -dot(n, s.d);
-    float cost2 = 1.0f - nn * nn * (1.0f - cost1 * cost1);
-    float m = 1.0f - cost1;
-    float m2 = m * m;
-    float rprob = r0 + (1.0f - r0) * (m2 * m2 * m);
-    bool refracted = (cost2 > 0.0f && u > rprob);
-    {   // one normalisation per lane: the vector is chosen first (sqrtf of a negative cost2 only feeds the side not taken)
+  } else {
+    // Mirror (:205-207, light::reflect) and glass (:208-213, light::refract) each choose a vector, then share ONE
+    // normalisation and ONE throughput update -- a wave that holds lanes of both would otherwise run the square root and the
+    // division twice.  Per lane the expressions are those of the two branches: cwise(T, (1, 1, 1)) is T exactly.
+    Vec3 v, tint = mk(1.f, 1.f, 1.f);
+    float wgt = rr;
+    if (type == MAT_SPECULAR) {
+      float cost = dot(s.d, n);
+      v = sub(s.d, scale(n, cost * 2.0f));
+    } else {
+      float u = uniform01(w[1], P.samples_half);
+      float nn = P.ri;
+      float r0 = (1.0f - nn) / (1.0f + nn);
+      r0 = r0 * r0;
+      if (dot(n, s.d) > 0.0f) { n = scale(n, -1.0f); nn = 1.0f / nn; }
+      nn = 1.0f / nn;
+      float cost1 = -dot(n, s.d);
+      float cost2 = 1.0f - nn * nn * (1.0f - cost1 * cost1);
+      float m = 1.0f - cost1;
+      float m2 = m * m;
+      float rprob = r0 + (1.0f - r0) * (m2 * m2 * m);
+      bool refracted = (cost2 > 0.0f && u > rprob);
+      // the vector is chosen first (sqrtf of a negative cost2 only feeds the side not taken)
       const Vec3 bent = add(scale(s.d, nn), scale(n, nn * cost1 - sqrtf(cost2)));
       const Vec3 mirrored = add(s.d, scale(n, cost1 * 2.0f));
-      s.d = normalise(refracted ? bent : mirrored);
+      v = refracted ? bent : mirrored;
+      if (refracted) tint = mk(cr, cg, cb);
+      wgt = 1.15f * rr;
     }
-    Vec3 tint = refracted ? mk(cr, cg, cb) : mk(1.f, 1.f, 1.f);
-    s.T = scale(cwise(s.T, tint), 1.15f * rr);
+    s.d = normalise(v);
+    s.T = scale(cwise(s.T, tint), wgt);
   }
   s.depth += 1u;                                              // :215
   if (s.depth >= P.max_path_length) {                         // stack full without an emitter (:173,:219-222)
@@ -394,6 +439,7 @@ __device__ __forceinline__ uint32_t pack_half2(float a, float b) {   // both are
 
 #ifdef PTMI_DIAG_BUILD
 }  // namespace ptd
+#include "diag/pt_trace_r3fn.h"
 #include "diag/pt_trace_rounds.h"   // round-4 experiment: the secondary phase in workgroup-synchronous, material-sorted rounds (not kept)
 namespace ptd {
 #endif
@@ -493,7 +539,12 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
       uint32_t w[4];
       philox4x32_10(st.pixel, st.sample, 1u, 0x5054u, P.seed_lo, P.seed_hi, w);   // the block of bounce 0; no roulette at depth 0
       uint32_t length = 0;
-      const int res = shade_hit(P, hit_table, st, (int)note.w, __uint_as_float(note.z), w, 1.0f, length);
+      int res;
+#ifdef PTMI_DIAG_BUILD
+      if constexpr ((OPT & 64) != 0) res = shade_hit_r3(P, hit_table, st, (int)note.w, __uint_as_float(note.z), w, 1.0f, length);
+      else
+#endif
+      res = shade_hit(P, hit_table, st, (int)note.w, __uint_as_float(note.z), w, 1.0f, length);
       if (res == STEP_CONTINUE) alive = true;
       else P.plen[idx] = (uint8_t)length;                                  // max_path_length = 1: the stack is full
     }
@@ -564,7 +615,7 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
     }
     int res = STEP_CONTINUE;
     uint32_t length = 0;
-    if (active) res = bounce(P, hit_table, st, length);
+    if (active) res = bounce<(OPT & 64) != 0>(P, hit_table, st, length);
     const bool ended = active && res != STEP_CONTINUE;
     const bool escaped = active && res == STEP_ESCAPED;
     if (ended) {

@@ -222,6 +222,8 @@ void fill_scene(ptd::TraceParams& P) {
     volatile float kx = (o.cx - 0.f) * o.nx, ky = (o.cy - 0.f) * o.ny, kz = (o.cz - 0.f) * o.nz;   // dot(sub(c, o), n)
     volatile float k0 = kx + ky, k1 = k0 + kz;
     o.kdisc = k1;
+    o.same_centre = (i > 0 && !src[i].disc && !src[i - 1].disc && src[i].c[0] == src[i - 1].c[0] && src[i].c[1] == src[i - 1].c[1] &&
+                     src[i].c[2] == src[i - 1].c[2]) ? 1 : 0;
   }
 }
 
