@@ -34,7 +34,7 @@ const Image3<std::uint8_t>& AccumulatedImage::updateLdrImage(std::size_t step, f
 
 void AccumulatedImage::saveImages(const std::string& fileName, std::size_t step, float exposure, float gamma) {
   const auto& ldr = updateLdrImage(step, exposure, gamma);
-  image_io::writePng(fileName, ldr.data.data(), ldr.cols, ldr.rows);
+  image_io::writeLdr(fileName, ldr.data.data(), ldr.cols, ldr.rows);   // cv::imwrite: the codec follows the extension
   // The accumulated image is divided by the number of steps so the integrand is divided by the total
   // sample count (each step added one per-pixel mean).
   Image3<float> scaled = hdrImage;

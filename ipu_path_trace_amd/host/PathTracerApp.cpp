@@ -1,4 +1,5 @@
 #include "PathTracerApp.hpp"
+#include "image_io.hpp"
 
 #include <sstream>
 
@@ -96,15 +97,11 @@ void PathTracerApp::init(const OptionMap& options) {
   if (args.u32("ipus") == 0) throw std::runtime_error("--ipus must be at least 1.");
   if (args.u32("save-interval") == 0) throw std::runtime_error("--save-interval must be at least 1.");
   if (samplesPerIpuStep == 0) throw std::runtime_error("--samples-per-step must be at least 1.");
-  {  // the reference hands --outfile to cv::imwrite, which picks the codec by extension; only the PNG writer is built in here
-    const std::string out = args.str("outfile");
-    const auto dot = out.find_last_of('.');
-    std::string ext = dot == std::string::npos ? std::string() : out.substr(dot);
-    std::transform(ext.begin(), ext.end(), ext.begin(), [](unsigned char c) { return (char)std::tolower(c); });
-    if (ext != ".png")
-      pt_log::warn_("--outfile '{}' does not end in .png: the low-dynamic-range image is written as PNG data all the same (the EXR goes to '{}.exr')",
-                    out, out.substr(0, dot));
-  }
+  // the reference hands --outfile to cv::imwrite, which picks the codec by extension (AccumulatedImage.cpp:49) and throws for one
+  // it has no writer for -- here before anything is rendered, not at the first save interval
+  if (!image_io::ldrWriterFor(args.str("outfile")))
+    throw std::runtime_error("--outfile '" + args.str("outfile") + "': could not find a writer for the specified extension "
+                             "(built in: .png .bmp .ppm .pnm .tif .tiff; the HDR image goes to <name>.exr)");
   if (!args.has("constant-env") || args.str("constant-env").empty()) {
     if (!loadNifModels(args.u32("ipus"), args.str("assets"))) throw std::runtime_error("Could not load NIF model.");
   }

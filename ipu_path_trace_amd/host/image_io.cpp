@@ -1,5 +1,9 @@
 #include "image_io.hpp"
 
+#include <zlib.h>
+
+#include <cctype>
+
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -56,6 +60,96 @@ void attr(std::vector<std::uint8_t>& v, const char* name, const char* type, cons
 
 }  // namespace
 
+namespace {
+std::string lowerExtension(const std::string& fileName) {
+  const auto dot = fileName.find_last_of('.');
+  std::string ext = dot == std::string::npos ? std::string() : fileName.substr(dot);
+  for (auto& c : ext) c = (char)std::tolower((unsigned char)c);
+  return ext;
+}
+std::ofstream openForWriting(const std::string& fileName) {
+  std::ofstream f(fileName, std::ios::binary);
+  if (!f) throw std::runtime_error("Could not open '" + fileName + "' for writing.");
+  return f;
+}
+void put16le(std::vector<std::uint8_t>& v, std::uint32_t x) { v.push_back(x & 0xff); v.push_back((x >> 8) & 0xff); }
+void put32le(std::vector<std::uint8_t>& v, std::uint32_t x) { put16le(v, x & 0xffff); put16le(v, x >> 16); }
+
+// 24-bit BMP, bottom-up rows padded to four bytes; pixels are B,G,R in the file as in memory
+void writeBmp(const std::string& fileName, const std::uint8_t* bgr8, std::size_t width, std::size_t height) {
+  auto f = openForWriting(fileName);
+  const std::size_t stride = (3 * width + 3) & ~std::size_t(3);
+  std::vector<std::uint8_t> h;
+  h.push_back('B'); h.push_back('M');
+  put32le(h, (std::uint32_t)(54 + stride * height)); put32le(h, 0); put32le(h, 54);
+  put32le(h, 40); put32le(h, (std::uint32_t)width); put32le(h, (std::uint32_t)height); put16le(h, 1); put16le(h, 24);
+  put32le(h, 0); put32le(h, (std::uint32_t)(stride * height)); put32le(h, 2835); put32le(h, 2835); put32le(h, 0); put32le(h, 0);
+  f.write((const char*)h.data(), (std::streamsize)h.size());
+  std::vector<std::uint8_t> row(stride, 0);
+  for (std::size_t r = height; r-- > 0;) {
+    std::copy(bgr8 + r * width * 3, bgr8 + (r + 1) * width * 3, row.begin());
+    f.write((const char*)row.data(), (std::streamsize)stride);
+  }
+}
+
+std::vector<std::uint8_t> toRgb(const std::uint8_t* bgr8, std::size_t pixels) {
+  std::vector<std::uint8_t> rgb(pixels * 3);
+  for (std::size_t i = 0; i < pixels; ++i) { rgb[3 * i] = bgr8[3 * i + 2]; rgb[3 * i + 1] = bgr8[3 * i + 1]; rgb[3 * i + 2] = bgr8[3 * i]; }
+  return rgb;
+}
+
+void writePpm(const std::string& fileName, const std::uint8_t* bgr8, std::size_t width, std::size_t height) {
+  auto f = openForWriting(fileName);
+  f << "P6\n" << width << " " << height << "\n255\n";
+  const auto rgb = toRgb(bgr8, width * height);
+  f.write((const char*)rgb.data(), (std::streamsize)rgb.size());
+}
+
+// Baseline TIFF, little-endian, one strip of uncompressed 8-bit RGB
+void writeTiff(const std::string& fileName, const std::uint8_t* bgr8, std::size_t width, std::size_t height) {
+  auto f = openForWriting(fileName);
+  const auto rgb = toRgb(bgr8, width * height);
+  std::vector<std::uint8_t> h;
+  h.push_back('I'); h.push_back('I'); put16le(h, 42); put32le(h, (std::uint32_t)(8 + rgb.size()));   // IFD behind the pixels
+  f.write((const char*)h.data(), 8);
+  f.write((const char*)rgb.data(), (std::streamsize)rgb.size());
+  std::vector<std::uint8_t> d;
+  const std::uint32_t ifd = (std::uint32_t)(8 + rgb.size()), nEntries = 10, bitsAt = ifd + 2 + nEntries * 12 + 4;
+  auto entry = [&](std::uint32_t tag, std::uint32_t type, std::uint32_t count, std::uint32_t value) {
+    put16le(d, tag); put16le(d, type); put32le(d, count);
+    if (type == 3 && count == 1) { put16le(d, value); put16le(d, 0); } else put32le(d, value);
+  };
+  put16le(d, nEntries);
+  entry(256, 4, 1, (std::uint32_t)width);        // ImageWidth
+  entry(257, 4, 1, (std::uint32_t)height);       // ImageLength
+  entry(258, 3, 3, bitsAt);                      // BitsPerSample -> 8, 8, 8
+  entry(259, 3, 1, 1);                           // Compression: none
+  entry(262, 3, 1, 2);                           // PhotometricInterpretation: RGB
+  entry(273, 4, 1, 8);                           // StripOffsets
+  entry(277, 3, 1, 3);                           // SamplesPerPixel
+  entry(278, 4, 1, (std::uint32_t)height);       // RowsPerStrip
+  entry(279, 4, 1, (std::uint32_t)rgb.size());   // StripByteCounts
+  entry(284, 3, 1, 1);                           // PlanarConfiguration: chunky
+  put32le(d, 0);                                 // no further IFD
+  put16le(d, 8); put16le(d, 8); put16le(d, 8);
+  f.write((const char*)d.data(), (std::streamsize)d.size());
+}
+}  // namespace
+
+bool ldrWriterFor(const std::string& fileName) {
+  const std::string e = lowerExtension(fileName);
+  return e == ".png" || e == ".bmp" || e == ".ppm" || e == ".pnm" || e == ".tif" || e == ".tiff";
+}
+
+void writeLdr(const std::string& fileName, const std::uint8_t* bgr8, std::size_t width, std::size_t height) {
+  const std::string e = lowerExtension(fileName);
+  if (e == ".png") writePng(fileName, bgr8, width, height);
+  else if (e == ".bmp") writeBmp(fileName, bgr8, width, height);
+  else if (e == ".ppm" || e == ".pnm") writePpm(fileName, bgr8, width, height);
+  else if (e == ".tif" || e == ".tiff") writeTiff(fileName, bgr8, width, height);
+  else throw std::runtime_error("could not find a writer for the specified extension of '" + fileName + "' (built in: .png .bmp .ppm .pnm .tif .tiff)");
+}
+
 void writePng(const std::string& fileName, const std::uint8_t* bgr8, std::size_t width, std::size_t height) {
   std::ofstream f(fileName, std::ios::binary);
   if (!f) throw std::runtime_error("Could not open '" + fileName + "' for writing.");
@@ -79,22 +173,11 @@ void writePng(const std::string& fileName, const std::uint8_t* bgr8, std::size_t
       row[1 + 3 * c + 2] = px[0];
     }
   }
-  // zlib stream of stored blocks
-  std::vector<std::uint8_t> z;
-  z.push_back(0x78); z.push_back(0x01);
-  std::uint32_t a = 1, b = 0;
-  for (std::size_t off = 0; off < raw.size() || off == 0; ) {
-    const std::size_t n = std::min<std::size_t>(65535, raw.size() - off);
-    const bool last = off + n >= raw.size();
-    z.push_back(last ? 1 : 0);
-    z.push_back(n & 0xff); z.push_back(n >> 8);
-    z.push_back(~n & 0xff); z.push_back((~n >> 8) & 0xff);
-    z.insert(z.end(), raw.begin() + off, raw.begin() + off + n);
-    for (std::size_t i = 0; i < n; ++i) { a = (a + raw[off + i]) % 65521u; b = (b + a) % 65521u; }
-    off += n;
-    if (last) break;
-  }
-  put32be(z, (b << 16) | a);
+  // zlib stream (deflate level 3; cv::imwrite's PNG default is a fast level too)
+  uLongf zlen = compressBound((uLong)raw.size());
+  std::vector<std::uint8_t> z(zlen);
+  if (compress2(z.data(), &zlen, raw.data(), (uLong)raw.size(), 3) != Z_OK) throw std::runtime_error("PNG: deflate failed for '" + fileName + "'.");
+  z.resize(zlen);
   chunk(f, "IDAT", z);
   chunk(f, "IEND", {});
 }

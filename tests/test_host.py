@@ -193,6 +193,15 @@ def test_film_accumulate_tonemap_and_exr(host, tmp_path):
     ww, hh = C.c_size_t(), C.c_size_t()
     assert host.pth_read_exr(str(tmp_path / "img.exr").encode(), back.ctypes.data, back.size, C.byref(ww), C.byref(hh)) == 0
     assert (ww.value, hh.value) == (w, h)
+    # cv::imwrite picks the codec by the file name's extension (AccumulatedImage.cpp:49): every built-in writer decodes to the
+    # same LDR image, and an extension without a writer is refused
+    for name in ("a.bmp", "a.PPM", "a.pnm", "a.tif", "a.TIFF"):
+        other = str(tmp_path / name)
+        assert host.pth_film_roundtrip(rec.ctypes.data, rec.size, w, h, steps, 0.5, 2.2, other.encode(), hdr.ctypes.data, ldr.ctypes.data) == 0
+        img = np.asarray(Image.open(other).convert("RGB"))
+        assert img.shape == (h, w, 3) and np.array_equal(img[..., ::-1], ldr), name
+    assert host.pth_film_roundtrip(rec.ctypes.data, rec.size, w, h, steps, 0.5, 2.2, str(tmp_path / "a.jpg").encode(), hdr.ctypes.data,
+                                   ldr.ctypes.data) != 0
     np.testing.assert_allclose(back, exp / steps, rtol=1e-6)
 
 
@@ -277,7 +286,7 @@ def test_cli_contract_without_gpu(host, tmp_path):
     assert not (tmp_path / "never.png").exists()
     r = subprocess.run([exe, "-o", str(tmp_path / "x.jpg"), "--assets", str(tmp_path), "--constant-env", "1,1,1", "--compile-only"],
                        capture_output=True, text=True)
-    assert r.returncode == 0 and "does not end in .png" in r.stdout      # cv::imwrite would pick JPEG; only PNG is built in: say so
+    assert r.returncode != 0 and "could not find a writer for the specified extension" in r.stdout   # cv::imwrite's refusal, at start-up
     r = subprocess.run([exe, "-o", str(tmp_path / "never.png"), "--assets", str(tmp_path), "--compile-only"], capture_output=True, text=True)
     assert r.returncode != 0 and "Could not load NIF model" in r.stdout      # a bad asset directory still fails the "compile"
 
