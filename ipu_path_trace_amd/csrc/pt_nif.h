@@ -882,13 +882,29 @@ __global__ void accumulate_kernel(uint32_t n, uint32_t iters, const uint8_t* ple
   uint32_t segs = 0, esc = 0;
   if (i < n) {
     float r = A.r[i], g = A.g[i], b = A.b[i];
-    for (uint32_t k = 0; k < iters; ++k) {
-      const size_t p = (size_t)k * n + i;
-      const uint32_t pl = plen[p];
-      segs += pl & 0x7fu;
-      if (pl & 0x80u) {
-        r += rad_r[p]; g += rad_g[p]; b += rad_b[p];   // :295-297
-        esc += 1;
+    // Eight iterations' loads are issued before the first add (a path's radiance is loaded whether or not it escaped: what a
+    // dead path left there is never added), so that the pass waits for memory once per eight iterations, not twice per one;
+    // the adds themselves stay in iteration order.
+    constexpr uint32_t U = 8;
+    for (uint32_t k0 = 0; k0 < iters; k0 += U) {
+      uint32_t pl[U];
+      float vr[U], vg[U], vb[U];
+#pragma unroll
+      for (uint32_t j = 0; j < U; ++j) {
+        const uint32_t k = (k0 + j < iters) ? k0 + j : iters - 1u;
+        const size_t p = (size_t)k * n + i;
+        pl[j] = plen[p];
+        vr[j] = rad_r[p]; vg[j] = rad_g[p]; vb[j] = rad_b[p];
+      }
+#pragma unroll
+      for (uint32_t j = 0; j < U; ++j) {
+        if (k0 + j < iters) {
+          segs += pl[j] & 0x7fu;
+          if (pl[j] & 0x80u) {
+            r += vr[j]; g += vg[j]; b += vb[j];      // :295-297
+            esc += 1;
+          }
+        }
       }
     }
     A.r[i] = r; A.g[i] = g; A.b[i] = b;
