@@ -102,7 +102,11 @@ int pt_create(const pt_config* cfg, pt_handle* out) {
   PT_HIPC(dev_alloc(&h->acc.count, n));
   PT_HIPC(dev_alloc(&h->acc.length, n));
   PT_HIPC(dev_alloc(&h->d_counters, 2));
-  const TraceGrid g = trace_grid((uint32_t)h->batch_paths_cap);
+  h->trace_blocks = std::min<uint32_t>((uint32_t)ptd::kMaxRegions, (uint32_t)pt_context::kTraceBlocksPerCu * (uint32_t)h->n_cus);
+#ifdef PTMI_DIAG_BUILD
+  if (const char* e = getenv("PTMI_TRACE_BLOCKS")) h->trace_blocks = std::min<uint32_t>((uint32_t)ptd::kMaxRegions, (uint32_t)std::max(1, atoi(e)));   // grid-size sweep of the profiling build
+#endif
+  const TraceGrid g = trace_grid((uint32_t)h->batch_paths_cap, h->trace_blocks);
   h->queue_cap = (size_t)g.blocks * g.region_cap;
   for (auto& B : h->bb) {
     PT_HIPC(dev_alloc(&B.q_u, h->queue_cap));
@@ -437,7 +441,7 @@ static int enqueue_path_trace(pt_handle h, std::vector<StageSpan>& spans, size_t
     uint32_t iters = std::min(h->iters_per_batch, h->samples_per_step - done);
     if (batch == 0 && !h->env_const && h->samples_per_step > 2u * h->iters_per_batch) iters = std::min(iters, h->first_batch_iters);
     const uint32_t total = iters * n;
-    const TraceGrid g = trace_grid(total);
+    const TraceGrid g = trace_grid(total, h->trace_blocks);
     pt_context::BatchBuffers& B = h->bb[batch & 1];
     P.sample_base = h->sample_cursor + done;
     P.total_paths = total;

@@ -67,6 +67,12 @@ struct pt_context {
   uint32_t first_batch_iters = 1;   // iterations of a step's first batch (see enqueue_path_trace)
   size_t batch_paths_cap = 0;
   size_t queue_cap = 0;
+  // Grid of the persistent trace kernel: six workgroups per CU (1536 on an MI355X).  Measured, scripts/sweep_trace_blocks.py:
+  // 9.1 ms per 331 M-path step for 1280...1536 workgroups against 10.2 for 1600...2048 (the grid of rounds 1-3), the C2 step
+  // unchanged -- the 60-VGPR / 106-SGPR kernel is resident six-fold per CU, not eight-fold as
+  // hipOccupancyMaxActiveBlocksPerMultiprocessor reports, so a larger grid runs its last workgroups on part of the chip.
+  static constexpr int kTraceBlocksPerCu = 6;
+  uint32_t trace_blocks = 1536;
   struct BatchBuffers {
     float *q_u = nullptr, *q_v = nullptr, *q_tr = nullptr, *q_tg = nullptr, *q_tb = nullptr;
     uint32_t* q_path = nullptr;
@@ -279,10 +285,11 @@ void bind_batch(ptd::TraceParams& P, const pt_context::BatchBuffers& B) {
 struct TraceGrid {
   uint32_t blocks, n_waves, region_cap;
 };
-TraceGrid trace_grid(uint32_t total) {
+// `cap` = pt_context::trace_blocks: the workgroups of the persistent trace kernel that are resident at once (pt_create).
+TraceGrid trace_grid(uint32_t total, uint32_t cap) {
   const uint32_t n_chunks = (total + 63u) / 64u;
   uint32_t blocks = (n_chunks + 3u) / 4u;
-  if (blocks > (uint32_t)ptd::kMaxRegions) blocks = ptd::kMaxRegions;
+  if (blocks > cap) blocks = cap;
   if (blocks == 0) blocks = 1;
   TraceGrid g;
   g.blocks = blocks;
