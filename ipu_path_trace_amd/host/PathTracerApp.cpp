@@ -101,7 +101,7 @@ void PathTracerApp::init(const OptionMap& options) {
   // it has no writer for -- here before anything is rendered, not at the first save interval
   if (!image_io::ldrWriterFor(args.str("outfile")))
     throw std::runtime_error("--outfile '" + args.str("outfile") + "': could not find a writer for the specified extension "
-                             "(built in: .png .bmp .ppm .pnm .tif .tiff; the HDR image goes to <name>.exr)");
+                             "(built in: .png .jpg .bmp .ppm .pnm .tif .tiff; the HDR image goes to <name>.exr)");
   if (!args.has("constant-env") || args.str("constant-env").empty()) {
     if (!loadNifModels(args.u32("ipus"), args.str("assets"))) throw std::runtime_error("Could not load NIF model.");
   }

@@ -10,8 +10,9 @@ namespace image_io {
 /// bgr8: height x width x 3 bytes in B,G,R order (OpenCV convention); written as an RGB PNG.
 void writePng(const std::string& fileName, const std::uint8_t* bgr8, std::size_t width, std::size_t height);
 /// The low-dynamic-range image as cv::imwrite(fileName, image) would save it (reference src/AccumulatedImage.cpp:49): the codec
-/// is chosen by the file name's extension, case-insensitive -- .png, .bmp, .ppm / .pnm (binary P6), .tif / .tiff (uncompressed
-/// RGB).  Any other extension throws, as cv::imwrite does for one it has no writer for (.jpg included: no JPEG encoder here).
+/// is chosen by the file name's extension, case-insensitive -- .png, .jpg / .jpeg / .jpe (baseline, quality 95, 4:4:4), .bmp,
+/// .ppm / .pnm (binary P6), .tif / .tiff (uncompressed RGB).  Any other extension throws, as cv::imwrite does for one it has no
+/// writer for.
 void writeLdr(const std::string& fileName, const std::uint8_t* bgr8, std::size_t width, std::size_t height);
 /// True if writeLdr has a writer for this file name (checked once at start-up, before anything is rendered).
 bool ldrWriterFor(const std::string& fileName);

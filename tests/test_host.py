@@ -200,7 +200,23 @@ def test_film_accumulate_tonemap_and_exr(host, tmp_path):
         assert host.pth_film_roundtrip(rec.ctypes.data, rec.size, w, h, steps, 0.5, 2.2, other.encode(), hdr.ctypes.data, ldr.ctypes.data) == 0
         img = np.asarray(Image.open(other).convert("RGB"))
         assert img.shape == (h, w, 3) and np.array_equal(img[..., ::-1], ldr), name
-    assert host.pth_film_roundtrip(rec.ctypes.data, rec.size, w, h, steps, 0.5, 2.2, str(tmp_path / "a.jpg").encode(), hdr.ctypes.data,
+    # JPEG is lossy: a smooth 40 x 27 image (not a multiple of 8: edge blocks) must come back within a few grey levels at quality 95
+    w2, h2 = 40, 27
+    rec2 = np.zeros(w2 * h2, dtype=TRACE_DTYPE)
+    r2, c2 = np.divmod(np.arange(w2 * h2), w2)
+    rec2["u"], rec2["v"] = c2, r2
+    rec2["r"] = (0.2 + 0.8 * c2 / w2) * 4
+    rec2["g"] = (0.2 + 0.8 * r2 / h2) * 4
+    rec2["b"] = (0.5 + 0.4 * np.sin(c2 / 5.0) * np.cos(r2 / 4.0)) * 4
+    rec2["sampleCount"] = 4
+    hdr2, ldr2 = np.zeros((h2, w2, 3), np.float32), np.zeros((h2, w2, 3), np.uint8)
+    for name in ("b.jpg", "b.JPEG"):
+        jp = str(tmp_path / name)
+        assert host.pth_film_roundtrip(rec2.ctypes.data, rec2.size, w2, h2, 1, 0.0, 2.2, jp.encode(), hdr2.ctypes.data, ldr2.ctypes.data) == 0
+        img = np.asarray(Image.open(jp).convert("RGB")).astype(np.int32)
+        err = np.abs(img[..., ::-1] - ldr2.astype(np.int32))
+        assert img.shape == (h2, w2, 3) and err.max() <= 12 and err.mean() < 2.0, (name, err.max(), err.mean())
+    assert host.pth_film_roundtrip(rec.ctypes.data, rec.size, w, h, steps, 0.5, 2.2, str(tmp_path / "a.webp").encode(), hdr.ctypes.data,
                                    ldr.ctypes.data) != 0
     np.testing.assert_allclose(back, exp / steps, rtol=1e-6)
 
@@ -284,7 +300,7 @@ def test_cli_contract_without_gpu(host, tmp_path):
                         "--save-exe", "graph"], capture_output=True, text=True)
     assert r.returncode == 0 and "Compile only mode selected: finished." in r.stdout, r.stdout[-500:]
     assert not (tmp_path / "never.png").exists()
-    r = subprocess.run([exe, "-o", str(tmp_path / "x.jpg"), "--assets", str(tmp_path), "--constant-env", "1,1,1", "--compile-only"],
+    r = subprocess.run([exe, "-o", str(tmp_path / "x.webp"), "--assets", str(tmp_path), "--constant-env", "1,1,1", "--compile-only"],
                        capture_output=True, text=True)
     assert r.returncode != 0 and "could not find a writer for the specified extension" in r.stdout   # cv::imwrite's refusal, at start-up
     r = subprocess.run([exe, "-o", str(tmp_path / "never.png"), "--assets", str(tmp_path), "--compile-only"], capture_output=True, text=True)
