@@ -323,3 +323,56 @@ def test_tile_costs_and_film_seed_contract(ptmi_lib):
     r.film_accumulate()
     np.testing.assert_array_equal(r.gather_hdr(rec.size, source=ptmi_lib.HDR_FILM)[0], seed + mean)
     r.close()
+
+
+def test_nif_calibration_and_kernel_name(oracle, ptmi_lib):
+    """ABI 4: pt_calibrate_nif re-runs the NIF stage of the last step's largest batch alone -- it must report that batch's
+    queue length, take a sane time, and leave the worklist's accumulators alone (a step after it continues exactly as a step
+    without it would); pt_nif_kernel_name names what the library dispatched for each kind of model.  Before any NIF step, and
+    with a constant environment only, there is nothing to calibrate: PT_ERR_NOT_READY."""
+    W = H = 64
+    layers, mx, mean = _nif()
+    r = ptmi_lib.Renderer(W, H, max_path_length=6)
+    assert r.nif_kernel_name() == ""
+    r.set_constant_env((1, 1, 1))
+    r.init_render_settings(samples_per_step=5)
+    rec = ptmi_lib.worklist(W, H)
+    r.setup(rec)
+    r.path_trace()
+    with pytest.raises(ptmi_lib.PtError) as e:
+        r.calibrate_nif()
+    assert e.value.code == -5
+    r.init_nif_weights(layers, 12, mx, mean)
+    with pytest.raises(ptmi_lib.PtError) as e:
+        r.calibrate_nif()                                    # a model, but no step with it yet
+    assert e.value.code == -5
+    r.setup(rec)
+    r.path_trace()
+    st = r.stats()
+    ms, evals = r.calibrate_nif(launches=3)
+    assert 0 < evals <= st.escaped and ms > 0                # one batch of the step (here the whole step: 5 iterations fit one batch... or its largest)
+    assert r.nif_kernel_name().startswith("nif_kernel_v3<320, 12")
+    r.path_trace()
+    got = ptmi_lib.worklist(W, H)
+    r.read_results(got)
+    # the same two steps without a calibration in between
+    r2 = ptmi_lib.Renderer(W, H, max_path_length=6)
+    r2.init_nif_weights(layers, 12, mx, mean)
+    r2.init_render_settings(samples_per_step=5)
+    r2.setup(rec)
+    r2.path_trace()                                          # r traced samples 0-4 with the constant sky first: skip them here too
+    r2.setup(rec)
+    r2.path_trace()
+    r2.path_trace()
+    want = ptmi_lib.worklist(W, H)
+    r2.read_results(want)
+    assert got.tobytes() == want.tobytes()
+    # the other two dispatch paths name themselves too
+    r.init_nif_weights(nif_assets.synthetic_nif(hidden=512, layer_count=3), 12, mx, mean)
+    r.nif_infer(np.array([0.3], np.float32), np.array([0.6], np.float32))
+    assert "nifg16_layer_kernel" in r.nif_kernel_name() and "hidden 512" in r.nif_kernel_name()
+    r.init_nif_weights(nif_assets.synthetic_nif(hidden=64, layer_count=3, dtype=np.float32), 12, mx, mean)
+    r.nif_infer(np.array([0.3], np.float32), np.array([0.6], np.float32))
+    assert "nif32_layer_kernel" in r.nif_kernel_name()
+    r.close()
+    r2.close()
