@@ -496,6 +496,11 @@ def main():
             ts["hbm_bytes_per_path"] = pmc.get("hbm_bytes_per_path")
             ts["achieved_hbm_GBps"] = (pmc["hbm_bytes_per_path"] * alone.paths / max(alone_s, 1e-9) / 1e9
                                        if pmc.get("hbm_bytes_per_path") else None)
+            if pmc.get("valu_busy_fraction"):
+                # the stage's own roofline statement: how much of all SIMD cycles the vector ALU is executing (the `frac` above
+                # prices every instruction at the guide's 2 cycles; Philox's 64-bit multiplies, divisions and square roots take 4x)
+                ts["valu_busy_fraction"] = pmc["valu_busy_fraction"]
+                ts["cycles_per_valu_wave_instr"] = pmc.get("cycles_per_valu_wave_instr")
             ts["counters_from"] = "%s (not measured in this run)" % pmc_src
         out["trace_stage"] = ts
         if calib and "error" not in calib:

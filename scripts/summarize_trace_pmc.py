@@ -47,6 +47,10 @@ def main():
         doc["lane_utilisation"] = sq["SQ_THREAD_CYCLES_VALU"] / (64.0 * sq["SQ_ACTIVE_INST_VALU"])
     if sq.get("GRBM_GUI_ACTIVE") and sq.get("SQ_ACTIVE_INST_VALU"):
         doc["gpu_cycles_total"] = sq["GRBM_GUI_ACTIVE"] / 8.0
+        # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the SIMDs; GRBM_GUI_ACTIVE sums the 8 XCDs; 1024 SIMDs
+        doc["valu_busy_fraction"] = 4.0 * sq["SQ_ACTIVE_INST_VALU"] / (sq["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+        if sq.get("SQ_INSTS_VALU"):
+            doc["cycles_per_valu_wave_instr"] = 4.0 * sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_INSTS_VALU"]
     if "FETCH_SIZE" in fetch and "WRITE_SIZE" in write:
         doc["FETCH_SIZE_KiB"] = fetch["FETCH_SIZE"]
         doc["WRITE_SIZE_KiB"] = write["WRITE_SIZE"]
