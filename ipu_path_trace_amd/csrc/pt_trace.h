@@ -24,6 +24,8 @@
 #pragma once
 #include "pt_device_math.h"
 
+#include <utility>
+
 namespace ptd {
 
 enum { MAT_DIFFUSE = 0, MAT_SPECULAR = 1, MAT_REFRACTIVE = 2 };
@@ -182,13 +184,17 @@ __device__ __forceinline__ float disc_intersect(Vec3 o, Vec3 d, const SceneObjec
 // loads, wave-uniform), instead of all of them living in SGPRs.
 // A sphere that shares its centre with the object declared before it (the clear-coat pair, codelets.cpp:115-116) reuses that
 // object's sub(o, c), dot(oc, d) and dot(oc, oc): the same expressions on the same values (wave-uniform flag from the host).
+template <bool PIPE = false>   // PIPE: the next object's constants are requested before this object's arithmetic, awaited after it
 __device__ __forceinline__ int nearest_hit(const TraceParams& P, Vec3 o, Vec3 d, float& tbest) {
   int best = -1;
   tbest = kInf;
   float b = 0.f, oc2 = 0.f;
+  SceneObject nxt = P.obj[0];
 #pragma unroll 1
   for (int i = 0; i < kNumObjects; ++i) {
-    const SceneObject ob = P.obj[i];
+    SceneObject ob;
+    if constexpr (PIPE) { ob = nxt; nxt = P.obj[i + 1 < kNumObjects ? i + 1 : kNumObjects - 1]; }
+    else ob = P.obj[i];
     float t;
     if (ob.is_disc) {
       t = disc_intersect(o, d, ob);
@@ -216,13 +222,17 @@ __device__ __forceinline__ int nearest_hit(const TraceParams& P, Vec3 o, Vec3 d,
 // constants, everything that depends on the direction is the expression of sphere_intersect / disc_intersect unchanged, so
 // the result is the same float.  (Disc: the hit point add(o, scale(d, t)) is scale(d, t) but for the sign of a zero, which
 // sub(p, c) and the squares that follow erase.)
+template <bool PIPE = false>
 __device__ __forceinline__ int nearest_hit_primary(const TraceParams& P, Vec3 d, float& tbest) {
   int best = -1;
   tbest = kInf;
   float b = 0.f;
+  SceneObject nxt = P.obj[0];
 #pragma unroll 1
   for (int i = 0; i < kNumObjects; ++i) {
-    const SceneObject ob = P.obj[i];
+    SceneObject ob;
+    if constexpr (PIPE) { ob = nxt; nxt = P.obj[i + 1 < kNumObjects ? i + 1 : kNumObjects - 1]; }
+    else ob = P.obj[i];
     float t;
     if (ob.is_disc) {
       const Vec3 n = mk(ob.nx, ob.ny, ob.nz), c = mk(ob.cx, ob.cy, ob.cz);
@@ -249,6 +259,42 @@ __device__ __forceinline__ int nearest_hit_primary(const TraceParams& P, Vec3 d,
   }
   return best;
 }
+
+
+// ---- The scene (src/codelets/codelets.cpp:111-144), ONE table for host and device: fill_scene (ptmi_context.h) copies it into the
+// kernel arguments, which is where the kernels read it (a rolled loop, one object's constants at a time in SGPRs).  Round 4
+// tried the object loop UNROLLED over this table -- every constant a literal, no scalar load, no s_waitcnt (39 % of the
+// kernel's wave-cycles sit in s_waitcnt) -- and lost: 90 VGPRs instead of 60 (five waves per SIMD, and no room beside the NIF
+// kernel's waves: the C2 step 2 % slower), 9.36 against 8.75 ms on its own (diag/pt_trace_scene_c.h, profiles/r04_trace_ablation.txt).
+struct SceneConst {
+  bool disc;
+  float cx, cy, cz, radius;
+  float nx, ny, nz;
+  float colr, colg, colb;
+  int type;
+};
+constexpr float kColourGain = 2.f;                                                                        // :127
+__host__ __device__ constexpr SceneConst scene_const(int i) {
+  constexpr SceneConst table[kNumObjects] = {
+      {false, -1.8575f, -0.98714f, -3.6f, 0.6f, 0.f, 0.f, 0.f, 1.f * kColourGain, .89f * kColourGain, .55f * kColourGain, MAT_DIFFUSE},      // :112,:128,:137
+      {false, 0.74795f, -0.55f, -4.3816f, 1.05f, 0.f, 0.f, 0.f, 1.f, 1.f, 1.f, MAT_SPECULAR},                                              // :113,:138
+      {false, 1.9929f, -1.08666f, (float)-3.23, 0.5f, 0.f, 0.f, 0.f, 0.75f, 0.75f, 0.75f, MAT_REFRACTIVE},                                 // :114,:131,:139
+      {false, (float)-0.19931, -1.183f, -2.75f, 0.4f, 0.f, 0.f, 0.f, .8f * kColourGain, .06f * kColourGain, .391f * kColourGain, MAT_DIFFUSE},   // :115,:129,:140
+      {false, (float)-0.19931, -1.183f, -2.75f, 0.4001f, 0.f, 0.f, 0.f, 1.f, 1.f, 1.f, MAT_REFRACTIVE},                                    // :116,:141
+      {true, 0.f, -1.6f, -5.22f, 3.5f, 0.f, 1.f, 0.f, .98f * kColourGain, .76f * kColourGain, .66f * kColourGain, MAT_DIFFUSE},             // :121,:130,:143
+  };
+  return table[i];
+}
+__host__ __device__ constexpr bool scene_same_centre(int i) {
+  return i > 0 && !scene_const(i).disc && !scene_const(i - 1).disc && scene_const(i).cx == scene_const(i - 1).cx &&
+         scene_const(i).cy == scene_const(i - 1).cy && scene_const(i).cz == scene_const(i - 1).cz;
+}
+
+#ifdef PTMI_DIAG_BUILD
+}  // namespace ptd
+#include "diag/pt_trace_scene_c.h"   // round-4 experiment: the object loop unrolled over the compile-time scene (not kept)
+namespace ptd {
+#endif
 
 enum StepResult { STEP_CONTINUE = 0, STEP_ESCAPED = 1, STEP_DEAD = 2 };
 
@@ -278,14 +324,14 @@ __device__ __forceinline__ int shade_hit(const TraceParams& P, const HitRow* tab
 // AccumulateContributions fold (codelets.cpp:255-292) carried forward as throughput T.
 // Returns the path length (contribution-stack size, codelets.cpp:253) through `length` when the
 // path ends.
-template <bool LEGACY = false>
+template <bool LEGACY = false, bool SCENE_C = false, bool PIPE = false>
 __device__ __forceinline__ int bounce(const TraceParams& P, const HitRow* tab, PathState& s, uint32_t& length);
 #ifdef PTMI_DIAG_BUILD
 __device__ __forceinline__ int nearest_hit_r3(const TraceParams& P, Vec3 o, Vec3 d, float& tbest);
 __device__ __forceinline__ int shade_hit_r3(const TraceParams& P, const HitRow* tab, PathState& s, int best, float tbest,
                                             const uint32_t (&w)[4], float rr, uint32_t& length);
 #endif
-template <bool LEGACY>
+template <bool LEGACY, bool SCENE_C, bool PIPE>
 __device__ __forceinline__ int bounce(const TraceParams& P, const HitRow* tab, PathState& s, uint32_t& length) {
   uint32_t w[4];
   philox4x32_10(s.pixel, s.sample, 1u + s.depth, 0x5054u, P.seed_lo, P.seed_hi, w);
@@ -304,7 +350,11 @@ __device__ __forceinline__ int bounce(const TraceParams& P, const HitRow* tab, P
   if constexpr (LEGACY) best = nearest_hit_r3(P, s.o, s.d, tbest);
   else
 #endif
-  best = nearest_hit(P, s.o, s.d, tbest);                     // Scene::intersect (:183)
+#ifdef PTMI_DIAG_BUILD
+  if constexpr (SCENE_C) best = nearest_hit_c(s.o, s.d, tbest, SceneIndices{});
+  else
+#endif
+  best = nearest_hit<PIPE>(P, s.o, s.d, tbest);               // Scene::intersect (:183)
   if (best < 0) {                                             // :184-190 ESCAPED
     s.T = scale(s.T, rr);
     length = s.depth + 1u;
@@ -451,10 +501,10 @@ namespace ptd {
 // instructions and 78.7 % lane utilisation, but no faster on its own (the VALU goes from 97 % to 84 % busy behind two
 // workgroup barriers per 256 paths) and 2 % slower inside the C2 step -- its 16 KiB of LDS do not fit beside the NIF
 // kernel's 157 KiB, so the trace kernel loses its place under the MFMA kernel (profiles/r04_trace_ablation.txt).
-constexpr int kTraceOpt = 3;
+constexpr int kTraceOpt = 3;   // (profiling build, bit 7: the object loop unrolled over the compile-time scene, diag/pt_trace_scene_c.h)
 template <uint32_t REFILL, int OPT = kTraceOpt>
 __device__ __forceinline__ void trace_body(const TraceParams& P) {
-  constexpr bool MAGIC = (OPT & 1) != 0, PRIMARY = (OPT & 2) != 0;
+  constexpr bool MAGIC = (OPT & 1) != 0, PRIMARY = (OPT & 2) != 0, SCENE_C = (OPT & 128) != 0, PIPE = (OPT & 256) != 0;
   __shared__ uint32_t wg_count;   // escaped paths queued by this workgroup
   __shared__ uint32_t wg_front, wg_back;   // camera rays of this workgroup that hit a diffuse / a mirror or glass object
   __shared__ uint32_t wg_state;            // survivors still alive after their first shading
@@ -485,7 +535,11 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
       uint32_t item, iter;
       split_index<MAGIC>(P, idx, item, iter);
       start_path(P, P.pix[item], P.sample_base + iter, st, camx, camy);
-      best = PRIMARY ? nearest_hit_primary(P, st.d, tbest) : nearest_hit(P, st.o, st.d, tbest);
+#ifdef PTMI_DIAG_BUILD
+      if constexpr (SCENE_C) best = nearest_hit_primary_c(st.d, tbest, SceneIndices{});
+      else
+#endif
+      best = PRIMARY ? nearest_hit_primary<PIPE>(P, st.d, tbest) : nearest_hit<PIPE>(P, st.o, st.d, tbest);
     }
     const bool hit = best >= 0;
     // a miss at depth 0 is final (codelets.cpp:184-190): one record, no roulette below roulette_depth >= 1, so the
@@ -615,7 +669,7 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
     }
     int res = STEP_CONTINUE;
     uint32_t length = 0;
-    if (active) res = bounce<(OPT & 64) != 0>(P, hit_table, st, length);
+    if (active) res = bounce<(OPT & 64) != 0, SCENE_C, PIPE>(P, hit_table, st, length);
     const bool ended = active && res != STEP_CONTINUE;
     const bool escaped = active && res == STEP_ESCAPED;
     if (ended) {

@@ -473,6 +473,10 @@ static int enqueue_path_trace(pt_handle h, std::vector<StageSpan>& spans, size_t
       hipLaunchKernelGGL(ptd::trace_kernel_opt<1>, dim3(g.blocks), dim3(ptd::kTraceBlock), 0, h->trace_stream, P);
     else if (tk && !strcmp(tk, "opt2"))
       hipLaunchKernelGGL(ptd::trace_kernel_opt<2>, dim3(g.blocks), dim3(ptd::kTraceBlock), 0, h->trace_stream, P);
+    else if (tk && !strcmp(tk, "pipe"))   // the next object's constants requested one object ahead
+      hipLaunchKernelGGL(ptd::trace_kernel_opt<259>, dim3(g.blocks), dim3(ptd::kTraceBlock), 0, h->trace_stream, P);
+    else if (tk && !strcmp(tk, "scenec"))   // the object loop unrolled over the compile-time scene (diag/pt_trace_scene_c.h)
+      hipLaunchKernelGGL(ptd::trace_kernel_opt<131>, dim3(g.blocks), dim3(ptd::kTraceBlock), 0, h->trace_stream, P);
     else if (tk && !strcmp(tk, "fn3"))   // the product's structure with round 3's intersect / shading functions (diag/pt_trace_r3fn.h)
       hipLaunchKernelGGL(ptd::trace_kernel_opt<67>, dim3(g.blocks), dim3(ptd::kTraceBlock), 0, h->trace_stream, P);
     else if (tk && !strcmp(tk, "rounds"))   // the secondary phase in workgroup-synchronous, material-sorted rounds (diag/pt_trace_rounds.h)

@@ -198,16 +198,12 @@ int ensure_scratch(pt_handle h, size_t bytes) {
 
 // Scene constants of src/codelets/codelets.cpp:111-144.
 void fill_scene(ptd::TraceParams& P) {
-  const float gain = 2.f;  // :127
   struct Src { int disc; float c[3]; float r; float col[3]; int type; };
-  const Src src[ptd::kNumObjects] = {
-      {0, {-1.8575f, -0.98714f, -3.6f}, 0.6f, {1.f * gain, .89f * gain, .55f * gain}, ptd::MAT_DIFFUSE},          // :112,:128,:137
-      {0, {0.74795f, -0.55f, -4.3816f}, 1.05f, {1.f, 1.f, 1.f}, ptd::MAT_SPECULAR},                                // :113,:138
-      {0, {1.9929f, -1.08666f, (float)-3.23}, 0.5f, {0.75f, 0.75f, 0.75f}, ptd::MAT_REFRACTIVE},                   // :114,:131,:139
-      {0, {(float)-0.19931, -1.183f, -2.75f}, 0.4f, {.8f * gain, .06f * gain, .391f * gain}, ptd::MAT_DIFFUSE},   // :115,:129,:140
-      {0, {(float)-0.19931, -1.183f, -2.75f}, 0.4001f, {1.f, 1.f, 1.f}, ptd::MAT_REFRACTIVE},                      // :116,:141
-      {1, {0.f, -1.6f, -5.22f}, 3.5f, {.98f * gain, .76f * gain, .66f * gain}, ptd::MAT_DIFFUSE},                  // :121,:130,:143
-  };
+  Src src[ptd::kNumObjects];
+  for (int i = 0; i < ptd::kNumObjects; ++i) {   // ONE table: the kernels' compile-time scene (pt_trace.h::scene_const, codelets.cpp:111-144)
+    const ptd::SceneConst S = ptd::scene_const(i);
+    src[i] = Src{S.disc ? 1 : 0, {S.cx, S.cy, S.cz}, S.radius, {S.colr, S.colg, S.colb}, S.type};
+  }
   for (int i = 0; i < ptd::kNumObjects; ++i) {
     ptd::SceneObject& o = P.obj[i];
     o.cx = src[i].c[0]; o.cy = src[i].c[1]; o.cz = src[i].c[2];
