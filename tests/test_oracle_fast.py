@@ -74,3 +74,39 @@ def test_c2_shape_render_matches_the_strict_build(fast):
         close = np.isclose(b[c][same], a[c][same], rtol=2e-2, atol=1e-4)
         assert close.mean() > 0.995                          # (a pixel whose two paths differ but have equal lengths: rare)
         assert abs(float(a[c].mean()) - float(b[c].mean())) < 1e-2 * float(a[c].mean())
+
+
+def test_the_avx2_block_of_the_timing_build(fast, tmp_path):
+    """The timing build has two NIF blocks, chosen by the compiler's target: 12 x 16 on AVX-512, 6 x 16 on AVX2.  A host with
+    AVX-512 (this one, the pool's boxes) only ever runs the first, so the second is built here with -mno-avx512f and checked
+    the same way -- a CPU without AVX-512 would otherwise run an untested path in bench.py's cpu_baseline leg."""
+    import ctypes as C
+    import os
+    import subprocess
+    if "AVX-512" not in fast.orc_build_info().decode():
+        pytest.skip("this host's own timing build already is the AVX2 one")
+    here = os.path.dirname(os.path.abspath(O.__file__))
+    so = str(tmp_path / "libpt_oracle_fast_avx2.so")
+    subprocess.check_call(["gcc", "-O3", "-march=native", "-mno-avx512f", "-std=gnu11", "-fPIC", "-shared", "-fopenmp", "-fno-math-errno",
+                           "-DORC_FAST_BUILD", "-o", so, os.path.join(here, "pt_oracle.c"), "-lm"])
+    lib = O._bind(C.CDLL(so))
+    assert "AVX2 6x16" in lib.orc_build_info().decode()
+    layers = nif_assets.synthetic_nif(hidden=96, layer_count=4)
+    meta, mean = nif_assets.URBAN_ALLEY_META, nif_assets.folded_mean()
+    strict = O.Nif(layers, 12, meta["max"], mean)
+    # a Nif bound to the AVX2 library by hand (O.Nif only knows the two builds of this host)
+    keep, arr = [], (O.LayerAny * len(layers))()
+    for i, (k, b, relu) in enumerate(layers):
+        k = np.ascontiguousarray(k, dtype=np.float16); b = np.ascontiguousarray(b, dtype=np.float16)
+        keep += [k, b]
+        arr[i].rows, arr[i].cols = k.shape
+        arr[i].kernel, arr[i].bias, arr[i].relu, arr[i].float32 = k.ctypes.data, b.ctypes.data, int(bool(relu)), 0
+    m = (C.c_float * 3)(*[float(x) for x in mean])
+    handle = lib.orc_nif_create_mixed(arr, len(layers), 12, float(meta["max"]), m, 1)
+    rng = np.random.default_rng(3)
+    n = 1000 + 37
+    u, v = rng.random(n, dtype=np.float32), rng.random(n, dtype=np.float32)
+    out = np.empty((n, 3), dtype=np.float32)
+    assert lib.orc_nif_infer(handle, u.ctypes.data, v.ctypes.data, n, out.ctypes.data) == 0
+    lib.orc_nif_destroy(handle)
+    np.testing.assert_allclose(out, strict.infer(u, v), rtol=2e-6, atol=1e-9)
