@@ -162,7 +162,7 @@ __device__ __forceinline__ void nif32_store(const NifF32Params& P, const f32x16 
   }
 }
 
-template <bool TWO>   // TWO: both 32-feature tiles of the block exist (false: the last block of a 32 (mod 64) wide layer)
+template <bool TWO, int MODE>   // TWO: both 32-feature tiles of the block exist (false: the last block of a 32 (mod 64) wide layer)
 __device__ __forceinline__ void nif32_block(const NifF32Params& P, float (*slice)[16][64], uint32_t tl, uint32_t f0) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t m = lane & 31u, kk = lane >> 5;
@@ -205,16 +205,13 @@ __device__ __forceinline__ void nif32_block(const NifF32Params& P, float (*slice
     *reinterpret_cast<float4*>(&slice[(it + 1u) & 1u][wr][wc]) = wn;   // read last in iteration it - 1, before its barrier
     __syncthreads();
   }
-  if (P.half_out) {        // mixed models only (uniform branches)
-    if (P.relu) nif32_store<TWO, true, 1>(P, acc, tl, f0, lane);
-    else nif32_store<TWO, false, 1>(P, acc, tl, f0, lane);
-  } else if (P.cast_half) {
-    if (P.relu) nif32_store<TWO, true, 2>(P, acc, tl, f0, lane);
-    else nif32_store<TWO, false, 2>(P, acc, tl, f0, lane);
-  } else if (P.relu) nif32_store<TWO, true>(P, acc, tl, f0, lane);
-  else nif32_store<TWO, false>(P, acc, tl, f0, lane);
+  if (P.relu) nif32_store<TWO, true, MODE>(P, acc, tl, f0, lane);
+  else nif32_store<TWO, false, MODE>(P, acc, tl, f0, lane);
 }
 
+// MODE: 0 = a float32 layer; mixed models only: 1 = a binary16 layer (P.half_out), 2 = a float32 layer whose successor is
+// binary16 (P.cast_half).  Separate instantiations: the all-float32 kernel keeps its 104 VGPRs (four waves per SIMD).
+template <int MODE>
 __global__ __launch_bounds__(256, 2) void nif32_layer_kernel(const NifF32Params P) {
   __shared__ float slice[2][16][64];
   const uint32_t ntiles = chunk_tile_count(P.total_tiles, P.tile0, P.chunk_tiles);
@@ -225,8 +222,8 @@ __global__ __launch_bounds__(256, 2) void nif32_layer_kernel(const NifF32Params 
   if (8u * sb >= ntiles) return;                            // the whole workgroup: no barrier is left waiting
   const uint32_t tl = 8u * sb + 2u * (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t f0 = col * 64u;
-  if (f0 + 32u < P.ldw) nif32_block<true>(P, slice, tl, f0);
-  else nif32_block<false>(P, slice, tl, f0);
+  if (f0 + 32u < P.ldw) nif32_block<true, MODE>(P, slice, tl, f0);
+  else nif32_block<false, MODE>(P, slice, tl, f0);
 }
 
 // Head (3 outputs) in float, decode (NifModel.cpp:221-245) and scatter (codelets.cpp:366-382).  One thread per sample, the

@@ -483,7 +483,10 @@ int launch_nif_f32(pt_handle h, const ptd::NifParams& N) {
         G.lda = h->f32_lda; G.ldf = h->f32_ldf;
         G.total_tiles = h->d_tile_start + N.n_regions; G.tile0 = (uint32_t)tile0; G.chunk_tiles = chunk;
         const uint32_t blocks = chunk / 8u * ((F.ldw + 63u) / 64u);  // one 256-sample x 64-feature block per workgroup
-        hipLaunchKernelGGL(ptd::nif32_layer_kernel, dim3((blocks + 7u) / 8u * 8u), dim3(256), 0, st, G);
+        const dim3 grid((blocks + 7u) / 8u * 8u);
+        if (F.half_out) hipLaunchKernelGGL(ptd::nif32_layer_kernel<1>, grid, dim3(256), 0, st, G);
+        else if (F.cast_half) hipLaunchKernelGGL(ptd::nif32_layer_kernel<2>, grid, dim3(256), 0, st, G);
+        else hipLaunchKernelGGL(ptd::nif32_layer_kernel<0>, grid, dim3(256), 0, st, G);
       } else {
         ptd::NifF32Head Hd{};
         Hd.w = h->d_f32_weights + F.w_off;
