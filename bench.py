@@ -14,6 +14,13 @@ Total work is fixed as N grows -> "scaling": "strong".
 it touches the GPU in any way, runs `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
 127.0.0.1 ... bench.py <same arguments>` as a CHILD process, relays its output (rank 0's JSON line) and exits with its
 code -- the reference's `--ipus N` is one command too (src/main.cpp:17-19, src/PathTracerApp.cpp:205-252).
+
+`--dist` (or BENCH_FORCE_DIST=1) makes `--gpus 1` take every branch of an N-rank run with the REAL backend: a child started
+by spawn_ranks(1), init_process_group("nccl"), the ncclUniqueId from rank 0 over torch.distributed, pt_comm_init_rank(id, 0,
+1), the all-reduced agreement, the warm-up product gather with its fallback switch, max-over-ranks on a CUDA tensor -- all of
+C4's orchestration that one GPU can execute (tests/test_multi_gpu_launch.py).  The bench line's `runtime` object says which
+librccl / libamdhip64 the process really bound (pt_runtime_info): torch is imported first here, so libptmi.so's imports of
+librccl.so.1 / libamdhip64.so.7 resolve to the copies PyTorch ships -- ONE HIP runtime per process, at every N.
 """
 import argparse
 import json
@@ -29,7 +36,7 @@ sys.path.insert(0, ROOT)
 MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense fp16/bf16
 
 
-VALU_PEAK_GWAVE_INSTR = 1024 * 2.4 / 2.0      # 1024 SIMD-32s x 2.4 GHz / 2 cycles per wave64 instruction (same guide)
+HBM_PEAK_GBPS = 8000.0                        # same guide: HBM3E ~8 TB/s
 
 
 def _profiles(pattern):
@@ -62,12 +69,12 @@ def trace_counters_from_profile(depth=8):
     return None, None
 
 
-def secondary_configs(ptmi, nif_assets, W, H, depth, meta, mean, spp=300):
+def secondary_configs(ptmi, nif_assets, W, H, depth, meta, mean, spp=300, steps=3):
     """Two more configurations measured in this run on the same image -- never the bench `value`, reported so that the
     numbers quoted for them in DESIGN.md / README.md can be checked against a driver-run line: BASELINE config C5 (NIF
     8 x 1024 fp16, the layer-by-layer path, 14,891,011 FLOP per evaluation) and the same 6 x 320 network with float32
-    variables (the float path, pt_nif_f32.h).  One warm-up step (30 spp) and one timed step of `spp` samples per pixel -- the
-    300 spp per step BASELINE states -- each."""
+    variables (the float path, pt_nif_f32.h).  One warm-up step (30 spp), then `steps` timed steps of `spp` samples per pixel
+    -- the 300 spp per step BASELINE states -- each; `value` is the MEDIAN step, min / max beside it."""
     out = {}
     for name, kw, peak in (("c5_nif_8x1024_fp16", dict(hidden=1024, layer_count=8), MFMA_F16_DENSE_PEAK_TFLOPS),
                            ("nif_6x320_float32", dict(hidden=320, layer_count=6, dtype=np.float32), 157.3)):
@@ -79,22 +86,56 @@ def secondary_configs(ptmi, nif_assets, W, H, depth, meta, mean, spp=300):
             r.setup(ptmi.worklist(W, H))
             r.path_trace()
             r.init_render_settings(samples_per_step=spp)
-            t = time.perf_counter()
-            r.path_trace()
-            dt = time.perf_counter() - t
-            st = r.stats()
+            rates, tfs, mss = [], [], []
+            for _ in range(steps):
+                t = time.perf_counter()
+                r.path_trace()
+                dt = time.perf_counter() - t
+                st = r.stats()
+                rates.append(st.paths / dt / 1e6)
+                mss.append(dt * 1e3)
+                tfs.append(st.escaped * st.nif_flops_per_sample / (st.nif_ms * 1e-3) / 1e12)
             kname = r.nif_kernel_name()
             r.close()
-            tf = st.escaped * st.nif_flops_per_sample / (st.nif_ms * 1e-3) / 1e12
-            out[name] = {"value": st.paths / dt / 1e6, "unit": "Mpath-samples/s", "spp_per_step": spp, "ms_per_step": dt * 1e3,
-                         "nif_flops_per_sample": int(st.nif_flops_per_sample), "nif_tflops": tf,
+            tf = float(np.median(tfs))
+            out[name] = {"value": float(np.median(rates)), "min": min(rates), "max": max(rates), "unit": "Mpath-samples/s",
+                         "steps": steps, "spp_per_step": spp, "ms_per_step": float(np.median(mss)),
+                         "nif_flops_per_sample": int(st.nif_flops_per_sample), "nif_tflops": tf, "nif_tflops_min": min(tfs),
                          "peak_tflops": peak, "frac": tf / peak, "kernel": kname}
         except Exception as e:   # noqa: BLE001 -- a secondary figure must never cost the headline line
             out[name] = {"error": str(e)}
     return out
 
 
-def cpu_baseline(ptmi, width, height, depth, layers, meta, mean, target_seconds=12.0):
+def c1_on_the_gpu(ptmi, steps=200):
+    """BASELINE configs[0] (256x256, 16 spp, depth 4, constant sky) on the GPU, for the table beside the CPU's rate.  One step
+    is 1 M paths -- about 0.1 ms of device work -- so what is measured is the host's cost per pt_path_trace call.  Timed
+    BEFORE any OpenMP region of this process exists (the oracle's 100+ worker threads keep spinning for a while after a
+    parallel region and would be timed instead): round 4's driver-run line had this leg 9x slower than the builder's for that
+    reason.  Host wall clock and the device's own time (pt_stats.total_ms: HIP events around the step) are both reported."""
+    g = ptmi.Renderer(256, 256, max_path_length=4)
+    g.set_constant_env((1.0, 1.0, 1.0))
+    g.init_render_settings(samples_per_step=16)
+    g.setup(ptmi.worklist(256, 256))
+    for _ in range(10):
+        g.path_trace()
+    t = time.perf_counter()
+    for _ in range(steps):
+        g.path_trace()
+    gdt = time.perf_counter() - t
+    dev_ms = []
+    for _ in range(20):                      # reading the stage times costs host time: outside the timed loop
+        g.path_trace()
+        dev_ms.append(g.stats().total_ms)
+    g.close()
+    paths = 256 * 256 * 16
+    return {"gpu_value": steps * paths / gdt / 1e6, "gpu_ms_per_step": gdt / steps * 1e3, "gpu_steps": steps,
+            "gpu_device_ms_per_step": float(np.median(dev_ms)), "gpu_value_device_time": paths / (float(np.median(dev_ms)) * 1e-3) / 1e6,
+            "gpu_what": "host wall over %d back-to-back pt_path_trace calls, measured before the CPU legs start their OpenMP "
+                        "threads; device time = pt_stats.total_ms (HIP events), median of 20 further steps" % steps}
+
+
+def cpu_baseline(width, height, depth, layers, meta, mean, c1_gpu, target_seconds=12.0):
     """The CPU beside the GPU number: the oracle's source -- a restatement, upstream
     external/light is not vendored -- in its TIMING build (oracle/Makefile: -O3 -march=native -fopenmp, contraction allowed,
     F16C conversions, NIF batches of 64 through a register-blocked AVX2 / AVX-512 kernel), compiled on this host, on all of
@@ -104,17 +145,22 @@ def cpu_baseline(ptmi, width, height, depth, layers, meta, mean, target_seconds=
     sample for reference.  `value` is the c2_shape rate: the same workload as the bench `value`."""
     from oracle import pt_oracle as O
     O.build()
-    fast = O.lib(fast=True)                              # builds libpt_oracle_fast.so for THIS host if need be
+    use_fast, fast_error = True, None
+    try:
+        fast = O.lib(fast=True)                          # builds libpt_oracle_fast.so for THIS host if need be
+    except Exception as e:   # noqa: BLE001 -- a host without AVX2 / F16C / FMA (oracle/Makefile's #error) or any other compile
+        # failure: the strict build is timed instead and the line says so -- a secondary figure never costs the headline
+        use_fast, fast_error, fast = False, str(e), O.lib()
     cores = int(fast.orc_max_threads())
     info = fast.orc_build_info().decode()
 
     # ---- c1: 256 x 256, 16 spp, depth 4, constant sky, seed 1 (no NIF)
     c1_cfg = O.make_config(width=256, height=256, max_path_length=4, env_mode=O.ENV_CONSTANT, env_rgb=(1.0, 1.0, 1.0))
     work = O.worklist(256, 256)
-    O.render(c1_cfg, None, work, 0, 16, fast=True)      # warm-up (threads, page faults)
+    O.render(c1_cfg, None, work, 0, 16, fast=use_fast)      # warm-up (threads, page faults)
     reps, paths, t = 0, 0, time.perf_counter()
     while True:
-        st = O.render(c1_cfg, None, work, 16 * (reps + 1), 16, fast=True)
+        st = O.render(c1_cfg, None, work, 16 * (reps + 1), 16, fast=use_fast)
         reps += 1
         paths += st.paths
         dt = time.perf_counter() - t
@@ -122,36 +168,22 @@ def cpu_baseline(ptmi, width, height, depth, layers, meta, mean, target_seconds=
             break
     c1 = {"value": paths / dt / 1e6, "unit": "Mpath-samples/s", "seconds": dt,
           "sample": "configs[0] in full: 256x256, 16 spp, depth 4, constant sky, %d repetitions" % reps}
-    try:                                                 # the GPU on the same config, for the same table (launch-bound: 1 M paths per step)
-        g = ptmi.Renderer(256, 256, max_path_length=4)
-        g.set_constant_env((1.0, 1.0, 1.0))
-        g.init_render_settings(samples_per_step=16)
-        g.setup(ptmi.worklist(256, 256))
-        g.path_trace()
-        t = time.perf_counter()
-        for _ in range(50):
-            g.path_trace()
-        gdt = time.perf_counter() - t
-        g.close()
-        c1["gpu_value"] = 50 * 256 * 256 * 16 / gdt / 1e6
-        c1["gpu_ms_per_step"] = gdt / 50 * 1e3
-    except Exception as e:   # noqa: BLE001 -- never cost the headline line
-        c1["gpu_error"] = str(e)
+    c1.update(c1_gpu)                                    # the GPU on the same config, measured earlier (c1_on_the_gpu)
 
     # ---- c2_shape: bounded pixel sample of the benchmark's workload
-    nif = O.Nif(layers, meta["embedding_dimension"], meta["max"], mean, fast=True)
+    nif = O.Nif(layers, meta["embedding_dimension"], meta["max"], mean, fast=use_fast)
     cfg = O.make_config(width=width, height=height, max_path_length=depth, env_mode=O.ENV_NIF)
     full = O.worklist(width, height)
     rng = np.random.default_rng(0)
     probe = full[rng.choice(full.size, min(full.size, 200000), replace=False)].copy()
     t = time.perf_counter()
-    O.render(cfg, nif, probe, 0, 1, fast=True)
+    O.render(cfg, nif, probe, 0, 1, fast=use_fast)
     rate = probe.size / (time.perf_counter() - t)
     n = int(min(full.size, max(20000, rate * target_seconds)))
     sample = full[rng.choice(full.size, n, replace=False)].copy()
     spp = int(min(64, max(1, round(rate * target_seconds / n))))
     t = time.perf_counter()
-    st = O.render(cfg, nif, sample, 0, spp, fast=True)
+    st = O.render(cfg, nif, sample, 0, spp, fast=use_fast)
     dt = time.perf_counter() - t
     flops = nif.flops_per_sample()
     c2 = {"value": st.paths / dt / 1e6, "unit": "Mpath-samples/s", "seconds": dt,
@@ -166,7 +198,7 @@ def cpu_baseline(ptmi, width, height, depth, layers, meta, mean, target_seconds=
     sdt = time.perf_counter() - t
     return {"value": c2["value"], "unit": "Mpath-samples/s", "cores": cores, "kind": "port",
             "sample": c2["sample"] + " (%.1f s of CPU work)" % dt,
-            "build_flags": info, "nproc": os.cpu_count(), "omp_max_threads": cores,
+            "build_flags": info, "nproc": os.cpu_count(), "omp_max_threads": cores, "timing_build_error": fast_error,
             "c1": c1, "c2_shape": c2,
             "strict_build": {"value": sst.paths / sdt / 1e6, "unit": "Mpath-samples/s", "seconds": sdt,
                              "build_flags": O.lib().orc_build_info().decode(),
@@ -217,10 +249,20 @@ def main():
     ap.add_argument("--dump-film", default="",
                     help="rank 0 writes the final film (float32 H x W x 3 BGR, mean radiance) to this .npy file; at one GPU the "
                          "film takes the same hand-off path (pt_gather_hdr of one tile) -- used by the tests to compare N ranks with one")
+    ap.add_argument("--dist", action="store_true",
+                    help="take the N-rank code path whatever --gpus says (with --gpus 1: everything an N-rank run does -- launcher, "
+                         "nccl process group, communicator from a broadcast unique id, product gather, max over ranks -- on one "
+                         "GPU); BENCH_FORCE_DIST=1 does the same")
+    ap.add_argument("--comm-fault", default="", choices=["", "corrupt-id"],
+                    help="TEST ONLY: damage the ncclUniqueId before pt_comm_init_rank, to exercise the agreed fallback to "
+                         "torch.distributed's gather (the bench line then says so)")
+    ap.add_argument("--comm-timeout-ms", type=int, default=60000,
+                    help="deadline of the communicator set-up and of every gather (pt_comm_set_timeout)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be at least 1")
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    dist_mode = args.dist or os.environ.get("BENCH_FORCE_DIST") == "1"
+    if (args.gpus > 1 or dist_mode) and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args.gpus))
 
     import torch
@@ -239,7 +281,8 @@ def main():
     rehearsal = os.environ.get("BENCH_REHEARSAL") == "1"
     device_index = 0 if rehearsal else local_rank
     torch.cuda.set_device(device_index)
-    if world > 1:
+    multi = world > 1 or dist_mode            # the N-rank code path (at world size 1 only with --dist)
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
             dist.init_process_group(backend="gloo")
@@ -256,7 +299,7 @@ def main():
 
     owner = partition.round_robin_owner(W, H, world)
     work = partition.worklist_for_owner(W, H, owner, rank)
-    redeal = args.enable_load_balancing and world > 1 and args.save_interval > 0
+    redeal = args.enable_load_balancing and multi and args.save_interval > 0
     counts = [partition.max_items_per_rank(W, H, world)] if redeal else partition.items_per_rank(W, H, world)
     stream = torch.cuda.current_stream().cuda_stream
     r = ptmi.Renderer(W, H, max_work_items=max(counts), max_path_length=depth, device=device_index, stream=stream)
@@ -274,18 +317,22 @@ def main():
     # the driver's launcher has set up anyway.  Should the communicator fail to come up on some rank, every rank falls
     # back to torch.distributed's gather of the same device buffers and the bench line says so.
     product_gather = False
-    COMM_TIMEOUT_MS = 60000   # a rank whose peers never arrive gives up after this long and everyone takes the fallback
+    COMM_TIMEOUT_MS = args.comm_timeout_ms   # a rank whose peers never arrive gives up after this long and everyone takes the fallback
 
     def everyone(ok):
         flag = torch.tensor([int(ok)], dtype=torch.int32, device="cuda")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         return bool(flag.item())
 
-    if world > 1 and not rehearsal:
+    if multi and not rehearsal:
         ok, why, uid = 1, "", None
         if rank == 0:
             try:
                 uid = ptmi.comm_unique_id()
+                if args.comm_fault == "corrupt-id":
+                    # TEST ONLY: an id no bootstrap root listens behind (ncclBootstrapHandle = magic u64, then the root's
+                    # socket address: the two port bytes are flipped)
+                    uid = uid[:10] + bytes([uid[10] ^ 0x5A, uid[11] ^ 0xA5]) + uid[12:]
             except Exception as e:   # noqa: BLE001 -- the other ranks still have to be told (they wait in the broadcast)
                 why = str(e)
         ids = [uid]
@@ -301,17 +348,17 @@ def main():
         product_gather = everyone(ok)
         gathered["via"] = ("pt_gather_hdr (RCCL inside libptmi.so)" if product_gather
                            else "torch.distributed gather (pt_comm_init_rank failed: %s)" % (why or "on another rank"))
-    elif world > 1:
+    elif multi:
         gathered["via"] = "gloo via host memory (rehearsal)"
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
     def gather_hdr(n_items):
         """One gather of HDR tiles to rank 0: mean BGR of the current accumulators, [world][slot][3] on rank 0."""
-        if world == 1:
+        if not multi:
             if args.dump_film:
                 gathered["tiles"] = r.gather_hdr(slot)                  # no communicator: export + copy of the one tile
             return
@@ -334,7 +381,7 @@ def main():
             gathered["tiles"] = np.stack([p_.cpu().numpy() for p_ in parts])
 
     film_sum = np.zeros((H, W, 3), dtype=np.float64) if rank == 0 else None   # sum over intervals of mean x steps
-    if args.dump_film and world == 1:
+    if args.dump_film and not multi:
         gathered["via"] = "pt_gather_hdr of one tile (no communicator)"
     state = {"owner": owner, "work": work, "steps_in_interval": 0}
 
@@ -342,7 +389,7 @@ def main():
         """Save-interval film hand-off (AccumulatedImage::accumulate, AccumulatedImage.cpp:59-74): mean BGR per work
         item -> one gather of HDR tiles to rank 0; optionally re-deal tiles by path length (N3) and start afresh."""
         gather_hdr(state["work"].size)
-        if rank == 0 and (world > 1 or args.dump_film) and (args.save_interval > 0):
+        if rank == 0 and (multi or args.dump_film) and (args.save_interval > 0):
             film = partition.assemble_hdr(W, H, world, gathered["tiles"], owner=state["owner"])
             film_sum[...] += film.astype(np.float64) * state["steps_in_interval"]
         if last or args.save_interval <= 0:
@@ -360,7 +407,7 @@ def main():
 
     for _ in range(args.warmup):
         r.path_trace()
-    if world > 1 and (args.warmup or product_gather):
+    if multi and (args.warmup or product_gather):
         # untimed: the first gather sets up RCCL's point-to-point channels (lazily, on first use); the timed hand-off
         # must measure the transfer, not the connection set-up.  It is also the proof that the product gather works on
         # this node: if it fails or times out on ANY rank, every rank switches to torch.distributed's gather.
@@ -399,7 +446,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     def max_over_ranks(x):
-        if world == 1:
+        if not multi:
             return x
         t = torch.tensor([x], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -412,7 +459,7 @@ def main():
     # differ by 5-7 %); `value_over_alone` = the rate inside the pipelined step / this rate moves only when the pipeline
     # around the kernel changes.  A slow box lowers both numbers; a regression lowers the ratio.
     calib = None
-    if rank == 0 and not (world > 1 and rehearsal):
+    if rank == 0 and not (multi and rehearsal):
         try:
             cal_ms, cal_evals = r.calibrate_nif(launches=4)
             calib = {"ms_per_launch": cal_ms, "evaluations_per_launch": int(cal_evals), "launches": 4}
@@ -479,28 +526,36 @@ def main():
                          "rank0_stage_ms": {"trace": agg["trace_ms"], "nif": agg["nif_ms"], "accumulate": agg["acc_ms"]}},
         }
         # Trace stage (ray-gen, intersect, shade, compact; accumulate is its own kernel).  Everything here is measured in
-        # this run except the two per-path constants, which come from the named PMC file.
+        # this run except the per-path constants, which come from the named PMC file.  Accounting as SURVEY.md 8(d) /
+        # BASELINE.md section 4 define it: algorithmic bytes = 96 B per path segment + 88 B per escaped path -- the traffic of
+        # a wavefront tracer that keeps ray state in HBM between bounces.  This design keeps it in registers, so the bytes
+        # the counters see are a fraction of that figure (avoided, not wasted) and the stage is bound by the vector ALU:
+        # ONE fraction is reported, the share of all SIMD cycles in which the VALU is executing.
         pmc, pmc_src = trace_counters_from_profile(depth)
         alone_s = alone.path_trace_ms * 1e-3
-        ts = {"bound": "valu", "unit": "G wave-instructions/s", "peak": VALU_PEAK_GWAVE_INSTR,
+        seg_step, esc_step = agg["segments"] / args.steps, agg["escaped"] / args.steps
+        ts = {"bound": "valu",
               "standalone_ms_per_step": alone.path_trace_ms, "standalone_accumulate_ms_per_step": alone.accumulate_ms,
               "standalone_Mpath_samples_per_s": alone.paths / max(alone_s, 1e-9) / 1e6,
               "overlapped_ms_per_step": agg["trace_ms"] / args.steps,
               "rays_per_sec": agg["segments"] * world / elapsed,
+              "algorithmic_bytes_per_step": 96.0 * seg_step + 88.0 * esc_step,
+              "algorithmic_bytes_model": "96 B x path segments + 88 B x escaped paths per step (SURVEY.md 8(d)): assumes ray state "
+                                         "travels through HBM between bounces; here it stays in registers",
               "what": "stand-alone = one constant-sky step of the same worklist in this run (no NIF kernel beside it); "
                       "overlapped = the trace kernels' own HIP-event time while the NIF kernel shares the CUs"}
         if pmc:
+            if pmc.get("hbm_bytes_per_path"):
+                ts["counter_bytes_per_step"] = pmc["hbm_bytes_per_path"] * agg["paths"] / args.steps
+                ts["counter_over_algorithmic"] = ts["counter_bytes_per_step"] / max(ts["algorithmic_bytes_per_step"], 1.0)
+                ts["achieved_hbm_GBps"] = pmc["hbm_bytes_per_path"] * alone.paths / max(alone_s, 1e-9) / 1e9
+                ts["hbm_peak_GBps"] = HBM_PEAK_GBPS
+            ts["frac"] = pmc.get("valu_busy_fraction")
+            ts["frac_is"] = "VALU busy: cycles the SIMDs spend executing vector instructions / all SIMD cycles of the launch"
             ts["valu_wave_instr_per_path"] = pmc["valu_wave_instr_per_path"]
-            ts["achieved"] = pmc["valu_wave_instr_per_path"] * alone.paths / max(alone_s, 1e-9) / 1e9
-            ts["frac"] = ts["achieved"] / VALU_PEAK_GWAVE_INSTR
-            ts["hbm_bytes_per_path"] = pmc.get("hbm_bytes_per_path")
-            ts["achieved_hbm_GBps"] = (pmc["hbm_bytes_per_path"] * alone.paths / max(alone_s, 1e-9) / 1e9
-                                       if pmc.get("hbm_bytes_per_path") else None)
-            if pmc.get("valu_busy_fraction"):
-                # the stage's own roofline statement: how much of all SIMD cycles the vector ALU is executing (the `frac` above
-                # prices every instruction at the guide's 2 cycles; Philox's 64-bit multiplies, divisions and square roots take 4x)
-                ts["valu_busy_fraction"] = pmc["valu_busy_fraction"]
-                ts["cycles_per_valu_wave_instr"] = pmc.get("cycles_per_valu_wave_instr")
+            ts["cycles_per_valu_wave_instr"] = pmc.get("cycles_per_valu_wave_instr")
+            ts["lane_utilisation"] = pmc.get("lane_utilisation")
+            ts["G_wave_instr_per_s"] = pmc["valu_wave_instr_per_path"] * alone.paths / max(alone_s, 1e-9) / 1e9
             ts["counters_from"] = "%s (not measured in this run)" % pmc_src
         out["trace_stage"] = ts
         if calib and "error" not in calib:
@@ -510,13 +565,33 @@ def main():
             out["roofline"]["value_over_alone"] = achieved / alone_tf if alone_tf > 0 else None
             out["roofline"]["nif_alone"] = dict(calib, what="pt_calibrate_nif: the NIF stage of the last step's largest batch re-run "
                                                 "alone on the device right after the timed steps (1 untimed + 4 timed launches)")
+            if traffic and not wide:
+                # algorithmic bytes of the launch the PMC figure describes (a full-size batch): 24 B of queue entry read +
+                # 12 B of radiance written per evaluation
+                out["roofline"]["algorithmic_bytes_per_launch"] = 36 * calib["evaluations_per_launch"]
+                out["roofline"]["traffic_over_algorithmic"] = traffic / (36.0 * calib["evaluations_per_launch"])
         elif calib:
             out["roofline"]["nif_alone"] = calib
-        if world == 1 and not args.no_secondary and not wide:
+        try:
+            out["runtime"] = dict(ptmi.runtime_info(), torch=torch.__version__, torch_hip=getattr(torch.version, "hip", None),
+                                  torch_imported_first=True,
+                                  what="the shared objects libptmi.so's HIP / RCCL imports are bound to in this process "
+                                       "(pt_runtime_info): torch is imported first, so they are the copies PyTorch ships")
+        except Exception as e:   # noqa: BLE001
+            out["runtime"] = {"error": str(e)}
+        if world == 1 and not args.no_secondary and not wide and not dist_mode:
             out["secondary"] = secondary_configs(ptmi, nif_assets, W, H, depth, meta, mean)
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(ptmi, W, H, depth, layers, meta, mean)
-        if world > 1 or args.dump_film:
+        if world == 1 and not args.no_cpu_baseline and not dist_mode:
+            # the GPU's rate on configs[0] first: the CPU legs start 100+ OpenMP threads that keep spinning afterwards
+            try:
+                c1_gpu = c1_on_the_gpu(ptmi)
+            except Exception as e:   # noqa: BLE001 -- never cost the headline line
+                c1_gpu = {"gpu_error": str(e)}
+            try:
+                out["cpu_baseline"] = cpu_baseline(W, H, depth, layers, meta, mean, c1_gpu)
+            except Exception as e:   # noqa: BLE001 -- e.g. the timing build does not compile on this host (oracle/Makefile needs AVX2 + F16C + FMA)
+                out["cpu_baseline"] = {"error": str(e), "c1": c1_gpu}
+        if multi or args.dump_film:
             if args.save_interval > 0:
                 film = (film_sum / args.steps).astype(np.float32)
                 out["config"]["save_interval"] = args.save_interval
@@ -533,7 +608,7 @@ def main():
             out["data"] = "synthetic (REHEARSAL on one shared GPU -- not a measurement)"
         print(json.dumps(out), flush=True)
     r.close()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PTMI_ABI_VERSION 4
+#define PTMI_ABI_VERSION 5
 
 typedef struct pt_context* pt_handle;
 
@@ -122,6 +122,15 @@ int pt_destroy(pt_handle h);
 /* Message for the last failure on `h` (or, with h == NULL, of the last failed pt_create). */
 const char* pt_last_error(pt_handle h);
 int pt_abi_version(void);
+/* ABI 5.  Which shared objects this process really bound the library's HIP and RCCL imports to, and their versions, as one
+ * JSON object: {"librccl": path, "libamdhip64": path, "rccl_version": ncclGetVersion() at run time, "rccl_compiled":
+ * NCCL_VERSION_CODE of the headers libptmi.so was built against, "hip_runtime_version", "hip_driver_version"}.  libptmi.so
+ * imports librccl.so.1 / libamdhip64.so.7 by SONAME: a process that has already loaded other copies under those names
+ * (PyTorch ships its own) gets THOSE -- a process holds one HIP runtime, whichever was loaded first.  The reference has no
+ * counterpart (its Poplar runtime is one library); the bench line and the tests record this so that nobody certifies one
+ * RCCL and measures on another.  Needs no handle and no device.  Always NUL-terminated; PT_ERR_INVALID_ARGUMENT if the
+ * buffer is too small (512 bytes are enough). */
+int pt_runtime_info(char* buf, size_t n);
 
 /* Program "init_nif_weights" (PathTracerApp.cpp:480; streams NifModel.cpp:375-401): all layer
  * kernels and biases, `max`, and `mean` with -eps already folded in (NifMetaData.cpp:48-53).
@@ -196,6 +205,10 @@ int pt_calibrate_nif(pt_handle h, uint32_t launches, double* ms_per_launch, uint
  * asynchronous error, or if another thread calls pt_comm_abort(h), the waiting rank aborts its communicator
  * (ncclCommAbort), drains its stream and returns PT_ERR_COMM; the handle then has no communicator and pt_gather_hdr
  * keeps returning PT_ERR_COMM until pt_comm_init_rank / pt_comm_init_all gives it a new one.  CONTRACT for callers
+ * pt_comm_init_rank / pt_comm_init_all ask the RCCL they are bound to for its version first (ncclGetVersion): older than
+ * 2.14 (no ncclCommInitRankConfig: a non-blocking communicator cannot be made) is refused with PT_ERR_COMM; older than the
+ * headers libptmi.so was compiled against, the ncclConfig_t is stamped with the RUNNING library's version, so that library
+ * reads exactly the fields it knows (DESIGN.md section 6 says which RCCL each entry point runs on).
  * that drive several ranks: when one rank's call fails, abort the others (pt_comm_abort -- the only pt_* function
  * that may be called from another thread while a call on the same handle is in progress) or let them time out.
  * Multi-rank exchanges have not been run on hardware yet (no multi-GPU box was available): DESIGN.md section 6. */

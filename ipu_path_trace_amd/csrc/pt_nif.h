@@ -54,6 +54,16 @@ __device__ __forceinline__ half8 as_half8(uint4 v) {
   return c.h;
 }
 
+// exp() of the decode (NifModel.cpp:239-241: popops::exp in float), full range: +inf above 88.72, SUBNORMAL results
+// between -87.3 and -103.3 (the fast intrinsic's v_exp_f32 flushes those to 0), NaN for NaN.  Three calls per sample
+// against a MFLOP of MLP: the accurate function costs nothing measurable.
+__device__ __forceinline__ float decode_exp(float x) { return expf(x); }
+
+// A LINEAR layer's "ReLU floor" for v_pk_max_f16: a quiet NaN.  max(x, qNaN) = x for every x, NaN included (with a floor
+// of -inf a NaN activation came out as -inf: the instruction returns the operand that is not a NaN) -- NifModel.cpp:323-325
+// applies no non-linearity at all to such a layer.
+constexpr uint32_t kLinearFloor = 0x7e007e00u;
+
 // sin and cos of a (|a| <= 8192) via two-constant reduction + v_sin/v_cos (revolutions).
 __device__ __forceinline__ void fast_sincos(float a, float& s, float& c) {
   float n = rintf(a * 0.15915494309189535f);
@@ -369,7 +379,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void nif_kernel_v2(const Nif
           for (int k = 0; k < 3; ++k) {
             float o = (float)o0[k] * P.max;
             o = o + mean[k];
-            bgr[k] = P.log_tonemap ? __expf(o) : o;
+            bgr[k] = P.log_tonemap ? decode_exp(o) : o;
           }
           const uint32_t qi = qbase + 32u * b + c;
           if (P.out_bgr) {
@@ -603,12 +613,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void nif_kernel_v3(const Nif
 
     // Epilogue of one tile in four chunks of four accumulator registers: fp32 -> fp16 (RNE, v_cvt_pk),
     // + bias in fp16 (v_pk_add_f16), ReLU (v_pk_max_f16): NifModel.cpp:314-325.  Branch-free: a linear
-    // layer uses a floor of -65504.  Chunk ch fills 32-bit words 2*(ch&1), 2*(ch&1)+1 of o0 (ch < 2) or o1.
+    // layer uses a floor that makes the max an identity (kLinearFloor).  Chunk ch fills 32-bit words 2*(ch&1), 2*(ch&1)+1 of o0 (ch < 2) or o1.
     typedef _Float16 half2v __attribute__((ext_vector_type(2)));
     struct Pending {
       f32x16 acc;
       const char* bias;   // this lane half's 32 bytes of packed bias
-      uint32_t floor;     // packed fp16 pair: 0 (ReLU) or -inf (linear)
+      uint32_t floor;     // packed fp16 pair: 0 (ReLU) or a quiet NaN (linear: kLinearFloor)
     };
     // Per-layer constants are fetched once per layer (layer_consts), not per tile: an s_load of a kernel argument
     // indexed by the layer can only be awaited with lgkmcnt(0), which would also drain the LDS reads in flight.
@@ -619,7 +629,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void nif_kernel_v3(const Nif
     auto layer_consts = [&](uint32_t layer) -> LayerConsts {
       LayerConsts c;
       c.bias = bias_lds + ((size_t)P.bias_base[layer] * 2 + h) * 32;
-      c.floor = ((P.relu_mask >> layer) & 1u) ? 0u : 0xfc00fc00u;
+      c.floor = ((P.relu_mask >> layer) & 1u) ? 0u : kLinearFloor;
       return c;
     };
     auto epi_begin = [&](Pending& p, const f32x16& acc, const LayerConsts& c, int j) __attribute__((always_inline)) {
@@ -647,7 +657,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void nif_kernel_v3(const Nif
         x0 = x0 + bb.hh[0];
         x1 = x1 + bb.hh[1];
       }
-      // ReLU as one v_pk_max_f16 against a uniform floor (0, or -inf for a linear layer: max(x, -inf) = x);
+      // ReLU as one v_pk_max_f16 against a uniform floor (0: max(NaN, 0) = 0 as the oracle's !(x > 0) -> 0; a linear layer: kLinearFloor);
       // the builtin max costs a canonicalising max and a select on top
       asm("v_pk_max_f16 %0, %1, %2" : "=v"(x0) : "v"(x0), "s"(p.floor));
       asm("v_pk_max_f16 %0, %1, %2" : "=v"(x1) : "v"(x1), "s"(p.floor));
@@ -803,7 +813,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void nif_kernel_v3(const Nif
         for (int k = 0; k < 3; ++k) {
           float o = (float)o0[k] * P.max;
           o = o + mean[k];
-          bgr[k] = P.log_tonemap ? __expf(o) : o;
+          bgr[k] = P.log_tonemap ? decode_exp(o) : o;
         }
         if (P.out_bgr) {
           P.out_bgr[3 * (size_t)qi + 0] = bgr[0];
@@ -845,14 +855,22 @@ struct Accum {
   uint32_t* length;    // pathLength
 };
 
-__global__ void unpack_records_kernel(const TraceRecordDev* rec, uint32_t n, Accum A) {
+// Also counts the items that are NOT padding (u < width and v < height, the test of AccumulatedImage.cpp:66) into *n_real:
+// padding items are not traced, and pt_stats.paths counts real paths only.
+__global__ void unpack_records_kernel(const TraceRecordDev* rec, uint32_t n, Accum A, uint32_t width, uint32_t height,
+                                      unsigned long long* n_real) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  TraceRecordDev t = rec[i];
-  A.pix[i] = (uint32_t)t.u | ((uint32_t)t.v << 16);
-  A.r[i] = t.r; A.g[i] = t.g; A.b[i] = t.b;
-  A.count[i] = t.sampleCount;
-  A.length[i] = t.pathLength;
+  bool real = false;
+  if (i < n) {
+    TraceRecordDev t = rec[i];
+    A.pix[i] = (uint32_t)t.u | ((uint32_t)t.v << 16);
+    A.r[i] = t.r; A.g[i] = t.g; A.b[i] = t.b;
+    A.count[i] = t.sampleCount;
+    A.length[i] = t.pathLength;
+    real = t.u < width && t.v < height;
+  }
+  const uint64_t m = __ballot(real);
+  if ((threadIdx.x & 63u) == 0 && m) atomicAdd(n_real, (unsigned long long)__popcll(m));
 }
 
 __global__ void pack_records_kernel(TraceRecordDev* rec, uint32_t n, Accum A) {
@@ -876,8 +894,24 @@ __global__ void clear_accum_kernel(uint32_t n, Accum A) {
 
 // AccumulateContributions::compute (codelets.cpp:249-301) for the k iterations of one batch, in
 // iteration order so the fp32 sums match the reference's (and the oracle's) order exactly.
-__global__ void accumulate_kernel(uint32_t n, uint32_t iters, const uint8_t* plen, const float* rad_r,
-                                  const float* rad_g, const float* rad_b, Accum A, unsigned long long* counters) {
+// Block reduction of the two step counters -> one 64-bit atomic pair per workgroup.
+__device__ __forceinline__ void accumulate_counters(uint32_t segs, uint32_t esc, unsigned long long* counters) {
+  __shared__ uint32_t ssegs[256], sesc[256];
+  ssegs[threadIdx.x] = segs; sesc[threadIdx.x] = esc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) { ssegs[threadIdx.x] += ssegs[threadIdx.x + s]; sesc[threadIdx.x] += sesc[threadIdx.x + s]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    atomicAdd(&counters[0], (unsigned long long)ssegs[0]);
+    atomicAdd(&counters[1], (unsigned long long)sesc[0]);
+  }
+}
+
+// One work item per thread: worklists whose size is not a multiple of four.
+__global__ __launch_bounds__(256) void accumulate_kernel(uint32_t n, uint32_t iters, const uint8_t* plen, const float* rad_r,
+                                                         const float* rad_g, const float* rad_b, Accum A, unsigned long long* counters) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t segs = 0, esc = 0;
   if (i < n) {
@@ -911,18 +945,58 @@ __global__ void accumulate_kernel(uint32_t n, uint32_t iters, const uint8_t* ple
     A.count[i] += iters;                                // :300
     A.length[i] += segs;                                // :253
   }
-  // block reduction of the two counters -> one 64-bit atomic pair per workgroup
-  __shared__ uint32_t ssegs[256], sesc[256];
-  ssegs[threadIdx.x] = segs; sesc[threadIdx.x] = esc;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) { ssegs[threadIdx.x] += ssegs[threadIdx.x + s]; sesc[threadIdx.x] += sesc[threadIdx.x + s]; }
-    __syncthreads();
+  accumulate_counters(segs, esc, counters);
+}
+
+// Four CONSECUTIVE work items per thread (n % 4 == 0, so path index k n + i is a multiple of four for every iteration k):
+// one 4-byte load of the four path records and three 16-byte loads of their radiance per iteration instead of four 1-byte
+// and twelve 4-byte ones -- a wave's load instruction covers 256 B / 1 KiB of consecutive memory, not 64 B / 256 B.  Each
+// pixel's adds are the same adds in the same (iteration) order: bit-identical to the kernel above.
+__global__ __launch_bounds__(256) void accumulate4_kernel(uint32_t n, uint32_t iters, const uint8_t* plen, const float* rad_r,
+                                                          const float* rad_g, const float* rad_b, Accum A, unsigned long long* counters) {
+  const uint32_t i = 4u * (blockIdx.x * blockDim.x + threadIdx.x);
+  uint32_t segs = 0, esc = 0;
+  if (i < n) {
+    float4 r = *reinterpret_cast<const float4*>(A.r + i), g = *reinterpret_cast<const float4*>(A.g + i),
+           b = *reinterpret_cast<const float4*>(A.b + i);
+    uint32_t len[4] = {0, 0, 0, 0};
+    constexpr uint32_t U = 4;   // iterations in flight per thread: 4 x 52 B
+    for (uint32_t k0 = 0; k0 < iters; k0 += U) {
+      uint32_t pl[U];
+      float4 vr[U], vg[U], vb[U];
+#pragma unroll
+      for (uint32_t j = 0; j < U; ++j) {
+        const uint32_t k = (k0 + j < iters) ? k0 + j : iters - 1u;
+        const size_t p = (size_t)k * n + i;
+        pl[j] = *reinterpret_cast<const uint32_t*>(plen + p);
+        vr[j] = *reinterpret_cast<const float4*>(rad_r + p);
+        vg[j] = *reinterpret_cast<const float4*>(rad_g + p);
+        vb[j] = *reinterpret_cast<const float4*>(rad_b + p);
+      }
+#pragma unroll
+      for (uint32_t j = 0; j < U; ++j) {
+        if (k0 + j < iters) {
+          const uint32_t w = pl[j];
+          len[0] += w & 0x7fu; len[1] += (w >> 8) & 0x7fu; len[2] += (w >> 16) & 0x7fu; len[3] += (w >> 24) & 0x7fu;
+          if (w & 0x80u) { r.x += vr[j].x; g.x += vg[j].x; b.x += vb[j].x; }               // :295-297
+          if (w & 0x8000u) { r.y += vr[j].y; g.y += vg[j].y; b.y += vb[j].y; }
+          if (w & 0x800000u) { r.z += vr[j].z; g.z += vg[j].z; b.z += vb[j].z; }
+          if (w & 0x80000000u) { r.w += vr[j].w; g.w += vg[j].w; b.w += vb[j].w; }
+          esc += (uint32_t)__popc(w & 0x80808080u);
+        }
+      }
+    }
+    *reinterpret_cast<float4*>(A.r + i) = r;
+    *reinterpret_cast<float4*>(A.g + i) = g;
+    *reinterpret_cast<float4*>(A.b + i) = b;
+    uint4 cnt = *reinterpret_cast<const uint4*>(A.count + i), ln = *reinterpret_cast<const uint4*>(A.length + i);
+    cnt.x += iters; cnt.y += iters; cnt.z += iters; cnt.w += iters;                        // :300
+    ln.x += len[0]; ln.y += len[1]; ln.z += len[2]; ln.w += len[3];                        // :253
+    *reinterpret_cast<uint4*>(A.count + i) = cnt;
+    *reinterpret_cast<uint4*>(A.length + i) = ln;
+    segs = len[0] + len[1] + len[2] + len[3];
   }
-  if (threadIdx.x == 0) {
-    atomicAdd(&counters[0], (unsigned long long)ssegs[0]);
-    atomicAdd(&counters[1], (unsigned long long)sesc[0]);
-  }
+  accumulate_counters(segs, esc, counters);
 }
 
 // (b, g, r) / sampleCount per work item: the value AccumulatedImage::accumulate adds

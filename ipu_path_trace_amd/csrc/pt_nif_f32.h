@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void nif32_head_kernel(const NifParams P, cons
       if (Hd.relu) o = o > 0.f ? o : 0.f;
       o = o * P.max;
       o = o + mean[k];
-      bgr[k] = P.log_tonemap ? __expf(o) : o;
+      bgr[k] = P.log_tonemap ? decode_exp(o) : o;
     }
     if (P.out_bgr) {
       P.out_bgr[3 * (size_t)qi + 0] = bgr[0];

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(512, 2) void nifg16_layer_kernel(const NifGemmParam
 
   // the output stores go through a buffer descriptor, for their cache-policy bits
   const auto out_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(P.act_out ? P.act_out : P.act_in), 0, 0x7fffffff, 0x00020000);
-  const uint32_t relu_floor = P.relu ? 0u : 0xfc00fc00u;   // packed fp16 pair
+  const uint32_t relu_floor = P.relu ? 0u : kLinearFloor;   // packed fp16 pair (pt_nif.h: a quiet NaN makes the max an identity)
   unsigned long long t_cycles = 0, t_real = 0;
   if constexpr (DIAG & 32) {
     if (blockIdx.x == 0 && threadIdx.x == 0) { t_cycles = __builtin_amdgcn_s_memtime(); t_real = __builtin_amdgcn_s_memrealtime(); }
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(512, 2) void nifg16_layer_kernel(const NifGemmParam
 #pragma unroll
         for (int i = 0; i < 4; ++i) { o[i] = (_Float16)acc[2 * s][b][i]; o[4 + i] = (_Float16)acc[2 * s + 1][b][i]; }
         o = o + bias;
-        {   // ReLU as one v_pk_max_f16 per register against a uniform floor: 0, or -inf for a linear layer (max(x, -inf) = x)
+        {   // ReLU as one v_pk_max_f16 per register against a uniform floor: 0, or kLinearFloor for a linear layer (max(x, qNaN) = x, NaN included)
           typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
           union { half8 hh; u32x4 u; } c;
           c.hh = o;
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(256) void nifg16_finish_kernel(const NifParams P, c
       if (Hd.relu) o16 = o16 > (_Float16)0.0f ? o16 : (_Float16)0.0f;
       float o = (float)o16 * P.max;
       o = o + mean[k];
-      bgr[k] = P.log_tonemap ? __expf(o) : o;
+      bgr[k] = P.log_tonemap ? decode_exp(o) : o;
     }
     if (P.out_bgr) {
       P.out_bgr[3 * (size_t)qi + 0] = bgr[0];

@@ -53,6 +53,7 @@ struct SceneObject {
 struct TraceParams {
   SceneObject obj[kNumObjects];
   float width_f, height_f;   // image size as float (pixelToRay)
+  uint32_t width, height;    // ... and as integers: an item with u >= width or v >= height is worklist padding (not traced)
   float tx, ty;              // tan(fov/2), (h/w) tan(fov/2)
   float aa_scale;            // half-rounded
   float stop_prob;           // half-rounded
@@ -527,19 +528,26 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
   // ---- primary phase: every lane starts a new path each trip (GenerateCameraRays + the first Scene::intersect)
   for (uint32_t j = 0; j < my_chunks; ++j) {
     const uint32_t idx = (j * P.n_waves + gw) * 64u + lane;
-    const bool valid = idx < P.total_paths;
+    bool valid = idx < P.total_paths;
     PathState st;
     float camx = 0.f, camy = 0.f, tbest = 0.f;
     int best = -1;
     if (valid) {
       uint32_t item, iter;
       split_index<MAGIC>(P, idx, item, iter);
-      start_path(P, P.pix[item], P.sample_base + iter, st, camx, camy);
+      const uint32_t pixel = P.pix[item];
+      // Worklist padding (LoadBalancer.cpp:66-71: u = v = 65535, "ignored during image accumulation", AccumulatedImage.cpp:66)
+      // is not traced: a path record of length 0, no radiance, no NIF evaluation -- the reference's tiles trace these items
+      // and throw the result away.
+      if ((pixel & 0xffffu) >= P.width || (pixel >> 16) >= P.height) { P.plen[idx] = 0; valid = false; }
+      else {
+        start_path(P, pixel, P.sample_base + iter, st, camx, camy);
 #ifdef PTMI_DIAG_BUILD
-      if constexpr (SCENE_C) best = nearest_hit_primary_c(st.d, tbest, SceneIndices{});
-      else
+        if constexpr (SCENE_C) best = nearest_hit_primary_c(st.d, tbest, SceneIndices{});
+        else
 #endif
-      best = PRIMARY ? nearest_hit_primary<PIPE>(P, st.d, tbest) : nearest_hit<PIPE>(P, st.o, st.d, tbest);
+        best = PRIMARY ? nearest_hit_primary<PIPE>(P, st.d, tbest) : nearest_hit<PIPE>(P, st.o, st.d, tbest);
+      }
     }
     const bool hit = best >= 0;
     // a miss at depth 0 is final (codelets.cpp:184-190): one record, no roulette below roulette_depth >= 1, so the
@@ -690,8 +698,6 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
 
 __global__ __launch_bounds__(kTraceBlock) void trace_kernel(const TraceParams P) { trace_body<kRefillThreshold>(P); }
 #ifdef PTMI_DIAG_BUILD
-template <uint32_t REFILL>
-__global__ __launch_bounds__(kTraceBlock) void trace_kernel_refill(const TraceParams P) { trace_body<REFILL>(P); }   // threshold sweep
 template <int OPT>
 __global__ __launch_bounds__(kTraceBlock) void trace_kernel_opt(const TraceParams P) { trace_body<kRefillThreshold, OPT>(P); }   // round-4 A/B (0 = the round-3 kernel; 7, 11: timing-only phase cuts)
 #endif

@@ -7,6 +7,9 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <dlfcn.h>
+#include <limits.h>
+
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -28,15 +31,16 @@
 #include "diag/pt_nif_variants.h"
 #endif
 #include "pt_trace.h"
-#ifdef PTMI_DIAG_BUILD
-#include "diag/pt_trace_v1.h"
-#endif
 
 #include "ptmi_context.h"
 #include "ptmi_nif_pack.h"
 #include "ptmi_nif_launch.h"
+#ifdef PTMI_DIAG_BUILD
+#include "diag/ptmi_trace_variants.h"
+#endif
 
-static void comm_release(pt_handle h);   // ptmi_film_comm.h: orderly end of the handle's communicator (finalize, polled; abort on expiry)
+static void comm_release(pt_handle h);
+static void forget_replay_state(pt_handle h);   // ptmi_film_comm.h: orderly end of the handle's communicator (finalize, polled; abort on expiry)
 
 extern "C" {
 
@@ -68,7 +72,7 @@ int pt_create(const pt_config* cfg, pt_handle* out) {
   pt_handle h = new pt_context();
   h->cfg = *cfg;
   auto bail = [&](int code) { g_create_error = h->error; pt_destroy(h); return code; };
-#define PT_HIPC(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { h->error = std::string(#call) + ": " + hipGetErrorString(e_); return bail(PT_ERR_HIP); } } while (0)
+#define PT_HIPC(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { h->error = std::string(#call) + ": " + hipGetErrorString(e_); return bail(hip_status(e_)); } } while (0)
   PT_HIPC(hipSetDevice(cfg->device));
   hipDeviceProp_t prop;
   PT_HIPC(hipGetDeviceProperties(&prop, cfg->device));
@@ -83,9 +87,19 @@ int pt_create(const pt_config* cfg, pt_handle* out) {
   const uint32_t n = cfg->max_work_items;
   h->capacity = n;
   uint32_t k = cfg->iterations_per_batch;
-  // auto: ~32 M paths per batch (2.5 GB of batch buffers at most -- small against 288 GB of HBM3E; larger batches
-  // mean fewer launch tails: 10 instead of 43 NIF launches per 300-spp step bought 2 %)
-  if (k == 0) { k = (uint32_t)((32u << 20) / n); if (k < 1) k = 1; if (k > 32) k = 32; }
+  // auto: as many sample iterations per batch as memory allows, 32 at most.  Both sets of batch buffers together cost
+  // kBatchBytesPerPath per path of capacity; the budget is 24 GiB or a quarter of what is free on the device, whichever is
+  // smaller -- small against 288 GB of HBM3E.  Larger batches mean fewer launch tails (10 instead of 43 NIF launches per
+  // 300-spp step of the 1104 x 1000 image bought 2 %) and fewer passes over the accumulators (a 3840 x 2160 image at the
+  // "32 M paths" of rounds 1-4 took 4 iterations per batch: 250 accumulate launches per 1000-spp step, each re-reading and
+  // re-writing 32 B of accumulators per item for 52 B of payload).
+  if (k == 0) {
+    size_t free_b = 0, total_b = 0;
+    uint64_t budget = 24ull << 30;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / 4 < budget) budget = free_b / 4;
+    const uint64_t paths = budget / pt_context::kBatchBytesPerPath;
+    k = (uint32_t)std::min<uint64_t>(32, std::max<uint64_t>(1, paths / n));
+  }
   if ((uint64_t)k * n >= (1ull << 31)) k = (uint32_t)(((1ull << 31) - 1) / n);
   if (k == 0) { h->error = "max_work_items too large"; return bail(PT_ERR_INVALID_ARGUMENT); }
   h->iters_per_batch = k;
@@ -101,7 +115,8 @@ int pt_create(const pt_config* cfg, pt_handle* out) {
   PT_HIPC(dev_alloc(&h->acc.b, n));
   PT_HIPC(dev_alloc(&h->acc.count, n));
   PT_HIPC(dev_alloc(&h->acc.length, n));
-  PT_HIPC(dev_alloc(&h->d_counters, 2));
+  PT_HIPC(dev_alloc(&h->d_counters, 3));   // segments, escaped (per step); real work items (per pt_setup)
+  PT_HIPC(hipHostMalloc(reinterpret_cast<void**>(&h->h_counters), 3 * sizeof(unsigned long long), hipHostMallocDefault));
   h->trace_blocks = std::min<uint32_t>((uint32_t)ptd::kMaxRegions, (uint32_t)pt_context::kTraceBlocksPerCu * (uint32_t)h->n_cus);
 #ifdef PTMI_DIAG_BUILD
   if (const char* e = getenv("PTMI_TRACE_BLOCKS")) h->trace_blocks = std::min<uint32_t>((uint32_t)ptd::kMaxRegions, (uint32_t)std::max(1, atoi(e)));   // grid-size sweep of the profiling build
@@ -152,6 +167,7 @@ int pt_destroy(pt_handle h) {
   (void)hipFree(h->d_records);
   (void)hipFree(h->acc.pix); (void)hipFree(h->acc.r); (void)hipFree(h->acc.g); (void)hipFree(h->acc.b); (void)hipFree(h->acc.count); (void)hipFree(h->acc.length);
   (void)hipFree(h->d_counters);
+  if (h->h_counters) (void)hipHostFree(h->h_counters);
   (void)hipFree(h->d_wpack); (void)hipFree(h->d_bpack);
   (void)hipFree(h->d_gemm_act[0]); (void)hipFree(h->d_gemm_act[1]); (void)hipFree(h->d_gemm_feat); (void)hipFree(h->d_tile_start);
   (void)hipFree(h->d_stamps);
@@ -247,6 +263,7 @@ static int upload_nif_f32(pt_handle h, const pt_layer* layers, uint32_t n_layers
   h->nif_flops = flops;
   h->nif_valid = true;
   h->env_const = false;
+  forget_replay_state(h);
   return PT_OK;
 }
 
@@ -369,6 +386,7 @@ int pt_upload_nif(pt_handle h, const pt_layer* layers, uint32_t n_layers, uint32
   h->nif_flops = flops;
   h->nif_valid = true;
   h->env_const = false;
+  forget_replay_state(h);
   return PT_OK;
 }
 
@@ -377,6 +395,7 @@ int pt_set_constant_env(pt_handle h, const float rgb[3]) {
   if (!rgb) return fail(h, PT_ERR_INVALID_ARGUMENT, "null rgb");
   h->env_const = true;
   memcpy(h->env_rgb, rgb, 12);
+  forget_replay_state(h);
   return PT_OK;
 }
 
@@ -403,23 +422,42 @@ int pt_setup(pt_handle h, const pt_trace_record* work, size_t n) {
   h->film_steps = 0;
   if (h->d_film) PT_HIP(hipMemsetAsync(h->d_film, 0, (size_t)h->capacity * 12, h->stream));   // a new worklist starts a new film
   if (h->tiles.n_tiles) PT_HIP(hipMemsetAsync(h->tiles.cost, 0, (size_t)h->tiles.n_tiles * 8, h->stream));   // ... and new per-tile sums
+  h->n_real = 0;
   if (n == 0) return PT_OK;
   static_assert(sizeof(pt_trace_record) == 20 && sizeof(ptd::TraceRecordDev) == 20, "TraceRecord wire format");
   PT_HIP(hipMemcpyAsync(h->d_records, work, n * sizeof(pt_trace_record), hipMemcpyHostToDevice, h->stream));
+  PT_HIP(hipMemsetAsync(h->d_counters + 2, 0, sizeof(unsigned long long), h->stream));
   hipLaunchKernelGGL(ptd::unpack_records_kernel, dim3(((uint32_t)n + 255) / 256), dim3(256), 0, h->stream, h->d_records,
-                     (uint32_t)n, h->acc);
+                     (uint32_t)n, h->acc, h->cfg.width, h->cfg.height, h->d_counters + 2);
   PT_HIP(hipGetLastError());
+  PT_HIP(hipMemcpyAsync(h->h_counters + 2, h->d_counters + 2, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
   PT_HIP(hipStreamSynchronize(h->stream));  // host buffer is not touched after return
+  h->n_real = (uint32_t)h->h_counters[2];   // items that are not padding: the only ones that are traced
   return PT_OK;
+}
+
+// AccumulateContributions for one batch: four consecutive items per thread where the worklist's size allows it.
+static void launch_accumulate(pt_handle h, uint32_t n, uint32_t iters, const pt_context::BatchBuffers& B) {
+  if (n % 4u == 0)
+    hipLaunchKernelGGL(ptd::accumulate4_kernel, dim3((n / 4u + 255) / 256), dim3(256), 0, h->acc_stream, n, iters, B.plen, B.rad_r,
+                       B.rad_g, B.rad_b, h->acc, h->d_counters);
+  else
+    hipLaunchKernelGGL(ptd::accumulate_kernel, dim3((n + 255) / 256), dim3(256), 0, h->acc_stream, n, iters, B.plen, B.rad_r,
+                       B.rad_g, B.rad_b, h->acc, h->d_counters);
 }
 
 // Enqueue the whole path_trace program on the three streams.  Returns at the first failing call; the caller drains the
 // streams either way, so a failure in the middle of the batch loop never leaves kernels running on buffers the host
 // is about to reuse or free.
-struct StageSpan { size_t a, b; int kind; };   // event pair around one stage of one batch: 0 trace, 1 NIF, 2 accumulate
+using StageSpan = pt_context::StageSpan;
+
+static void forget_replay_state(pt_handle h) {   // pt_calibrate_nif may only replay a batch of the most recent NIF step
+  for (auto& B : h->bb) { B.last_paths = 0; B.last_regions = 0; B.last_region_cap = 0; }
+}
 
 static int enqueue_path_trace(pt_handle h, std::vector<StageSpan>& spans, size_t& e_begin_i, size_t& e_end_i) {
   const uint32_t n = h->n_items;
+  forget_replay_state(h);
   PT_HIP(hipMemsetAsync(h->d_counters, 0, 2 * sizeof(unsigned long long), h->stream));
   ptd::TraceParams P;
   fill_trace_params(h, P);
@@ -434,12 +472,19 @@ static int enqueue_path_trace(pt_handle h, std::vector<StageSpan>& spans, size_t
   if (!e_begin) return fail(h, PT_ERR_HIP, "hipEventCreate failed");
   PT_HIP(hipEventRecord(e_begin, h->stream));
   PT_HIP(hipStreamWaitEvent(h->trace_stream, e_begin, 0));   // counters memset and earlier work on `stream`
+  // Batches.  The first batch is kept short when the step has several: its trace kernel is the only one with no NIF kernel
+  // to hide under, so the sooner it ends the sooner the MFMA pipes start.  The remaining iterations are dealt EVENLY over as
+  // few batches as the capacity allows (sizes differ by one at most), so no step ends on a stub of a batch whose launch
+  // tails weigh as much as a full one's.  Per-pixel sums stay in iteration order whatever the split.
+  const uint32_t spp = h->samples_per_step;
+  const uint32_t first = (!h->env_const && spp > 2u * h->iters_per_batch) ? std::min(h->first_batch_iters, h->iters_per_batch) : 0u;
+  const uint32_t rest = spp - first;
+  const uint32_t rest_batches = (rest + h->iters_per_batch - 1u) / h->iters_per_batch;
+  const uint32_t base = rest_batches ? rest / rest_batches : 0u, longer = rest_batches ? rest % rest_batches : 0u;
   uint32_t done = 0, batch = 0;
-  while (done < h->samples_per_step) {
-    // The first batch is kept short when the step has several: its trace kernel is the only one with no NIF kernel to
-    // hide under, so the sooner it ends the sooner the MFMA pipes start (per-pixel sums stay in iteration order).
-    uint32_t iters = std::min(h->iters_per_batch, h->samples_per_step - done);
-    if (batch == 0 && !h->env_const && h->samples_per_step > 2u * h->iters_per_batch) iters = std::min(iters, h->first_batch_iters);
+  while (done < spp) {
+    const uint32_t r = batch - (first ? 1u : 0u);                       // index among the evenly dealt batches
+    const uint32_t iters = (first && batch == 0) ? first : base + (r < longer ? 1u : 0u);
     const uint32_t total = iters * n;
     const TraceGrid g = trace_grid(total, h->trace_blocks);
     pt_context::BatchBuffers& B = h->bb[batch & 1];
@@ -455,43 +500,7 @@ static int enqueue_path_trace(pt_handle h, std::vector<StageSpan>& spans, size_t
     if (batch >= 2) PT_HIP(hipStreamWaitEvent(h->trace_stream, B.accumulated, 0));
     PT_HIP(hipEventRecord(t0, h->trace_stream));
 #ifdef PTMI_DIAG_BUILD
-    // A/B switch of the profiling build, read per launch: the round-2 one-phase kernel
-    const char* tk = getenv("PTMI_TRACE_KERNEL");
-    if (tk && !strcmp(tk, "v1"))
-      hipLaunchKernelGGL(ptd::trace_kernel_v1, dim3(g.blocks), dim3(ptd::kTraceBlock), 0, h->trace_stream, P);
-    else if (tk && !strcmp(tk, "r1"))
-      hipLaunchKernelGGL(ptd::trace_kernel_refill<1>, dim3(g.blocks), dim3(ptd::kTraceBlock), 0, h->trace_stream, P);
-    else if (tk && !strcmp(tk, "r4"))
-      hipLaunchKernelGGL(ptd::trace_kernel_refill<4>, dim3(g.blocks), dim3(ptd::kTraceBlock), 0, h->trace_stream, P);
-    else if (tk && !strcmp(tk, "r16"))
-      hipLaunchKernelGGL(ptd::trace_kernel_refill<16>, dim3(g.blocks), dim3(ptd::kTraceBlock), 0, h->trace_stream, P);
-    else if (tk && !strcmp(tk, "r24"))
-      hipLaunchKernelGGL(ptd::trace_kernel_refill<24>, dim3(g.blocks), dim3(ptd::kTraceBlock), 0, h->trace_stream, P);
-    else if (tk && !strcmp(tk, "opt0"))   // the round-3 kernel: neither round-4 change
-      hipLaunchKernelGGL(ptd::trace_kernel_opt<0>, dim3(g.blocks), dim3(ptd::kTraceBlock), 0, h->trace_stream, P);
-    else if (tk && !strcmp(tk, "opt1"))
-      hipLaunchKernelGGL(ptd::trace_kernel_opt<1>, dim3(g.blocks), dim3(ptd::kTraceBlock), 0, h->trace_stream, P);
-    else if (tk && !strcmp(tk, "opt2"))
-      hipLaunchKernelGGL(ptd::trace_kernel_opt<2>, dim3(g.blocks), dim3(ptd::kTraceBlock), 0, h->trace_stream, P);
-    else if (tk && !strcmp(tk, "pipe"))   // the next object's constants requested one object ahead
-      hipLaunchKernelGGL(ptd::trace_kernel_opt<259>, dim3(g.blocks), dim3(ptd::kTraceBlock), 0, h->trace_stream, P);
-    else if (tk && !strcmp(tk, "scenec"))   // the object loop unrolled over the compile-time scene (diag/pt_trace_scene_c.h)
-      hipLaunchKernelGGL(ptd::trace_kernel_opt<131>, dim3(g.blocks), dim3(ptd::kTraceBlock), 0, h->trace_stream, P);
-    else if (tk && !strcmp(tk, "fn3"))   // the product's structure with round 3's intersect / shading functions (diag/pt_trace_r3fn.h)
-      hipLaunchKernelGGL(ptd::trace_kernel_opt<67>, dim3(g.blocks), dim3(ptd::kTraceBlock), 0, h->trace_stream, P);
-    else if (tk && !strcmp(tk, "rounds"))   // the secondary phase in workgroup-synchronous, material-sorted rounds (diag/pt_trace_rounds.h)
-      hipLaunchKernelGGL(ptd::trace_kernel_opt<35>, dim3(g.blocks), dim3(ptd::kTraceBlock), 0, h->trace_stream, P);
-    else if (tk && !strcmp(tk, "count")) {   // secondary-phase occupancy counters into the stamp buffer (pt_diag_stamps)
-      if (!h->d_stamps) { PT_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_stamps), 256 * 8)); PT_HIP(hipMemset(h->d_stamps, 0, 256 * 8)); }
-      ptd::TraceParams PC = P;
-      PC.diag = h->d_stamps;
-      hipLaunchKernelGGL(ptd::trace_kernel_opt<19>, dim3(g.blocks), dim3(ptd::kTraceBlock), 0, h->trace_stream, PC);
-    }
-    else if (tk && !strcmp(tk, "cut2"))   // timing only: no secondary phase
-      hipLaunchKernelGGL(ptd::trace_kernel_opt<7>, dim3(g.blocks), dim3(ptd::kTraceBlock), 0, h->trace_stream, P);
-    else if (tk && !strcmp(tk, "cut1"))   // timing only: primary phase alone
-      hipLaunchKernelGGL(ptd::trace_kernel_opt<11>, dim3(g.blocks), dim3(ptd::kTraceBlock), 0, h->trace_stream, P);
-    else
+    if (!launch_trace_variant(h, P, g))   // A/B switches of the profiling build (diag/ptmi_trace_variants.h), read per launch
 #endif
     hipLaunchKernelGGL(ptd::trace_kernel, dim3(g.blocks), dim3(ptd::kTraceBlock), 0, h->trace_stream, P);
     PT_HIP(hipGetLastError());
@@ -522,8 +531,7 @@ static int enqueue_path_trace(pt_handle h, std::vector<StageSpan>& spans, size_t
     PT_HIP(hipEventRecord(n1, h->stream));
     PT_HIP(hipStreamWaitEvent(h->acc_stream, n1, 0));
     PT_HIP(hipEventRecord(a0, h->acc_stream));
-    hipLaunchKernelGGL(ptd::accumulate_kernel, dim3((n + 255) / 256), dim3(256), 0, h->acc_stream, n, iters, B.plen, B.rad_r,
-                       B.rad_g, B.rad_b, h->acc, h->d_counters);
+    launch_accumulate(h, n, iters, B);
     PT_HIP(hipGetLastError());
     PT_HIP(hipEventRecord(a1, h->acc_stream));
     PT_HIP(hipEventRecord(B.accumulated, h->acc_stream));
@@ -538,10 +546,31 @@ static int enqueue_path_trace(pt_handle h, std::vector<StageSpan>& spans, size_t
   if (!e_acc) return fail(h, PT_ERR_HIP, "hipEventCreate failed");
   PT_HIP(hipEventRecord(e_acc, h->acc_stream));
   PT_HIP(hipStreamWaitEvent(h->stream, e_acc, 0));          // later work on `stream` sees the accumulated film
+  // the two counters travel to pinned host memory on the stream itself: the host waits once, for e_end
+  PT_HIP(hipMemcpyAsync(h->h_counters, h->d_counters, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
   e_end_i = ev;
   hipEvent_t e_end = get_event(h, ev++);
   if (!e_end) return fail(h, PT_ERR_HIP, "hipEventCreate failed");
   PT_HIP(hipEventRecord(e_end, h->stream));
+  return PT_OK;
+}
+
+// Per-stage device times of the last step from its event pairs; read on demand (pt_get_stats, pt_read_results,
+// pt_calibrate_nif -- which reuses two of the events).  The events are complete: pt_path_trace returned after e_end.
+static int resolve_stage_times(pt_handle h) {
+  if (!h->spans_pending) return PT_OK;
+  h->spans_pending = false;
+  PT_HIP(hipSetDevice(h->cfg.device));
+  for (const StageSpan& s : h->spans) {
+    float ms = 0.f;
+    PT_HIP(hipEventElapsedTime(&ms, h->events[s.a], h->events[s.b]));
+    if (s.kind == 0) h->stats.path_trace_ms += ms;
+    else if (s.kind == 1) h->stats.nif_ms += ms;
+    else h->stats.accumulate_ms += ms;
+  }
+  float total_ms = 0.f;
+  PT_HIP(hipEventElapsedTime(&total_ms, h->events[h->e_begin_i], h->events[h->e_end_i]));
+  h->stats.total_ms = total_ms;
   return PT_OK;
 }
 
@@ -551,39 +580,33 @@ int pt_path_trace(pt_handle h) {
   if (!h->env_const && !h->nif_valid) return fail(h, PT_ERR_NOT_READY, "no environment: call pt_upload_nif or pt_set_constant_env");
   PT_HIP(hipSetDevice(h->cfg.device));
   memset(&h->stats, 0, sizeof(h->stats));
+  h->spans_pending = false;
   h->stats.nif_flops_per_sample = h->env_const ? 0 : h->nif_flops;
   h->stats.first_sample = h->sample_cursor;
   const uint32_t n = h->n_items;
   if (n == 0) return PT_OK;
 
-  std::vector<StageSpan> spans;
-  size_t e_begin_i = 0, e_end_i = 0;
-  const int rc = enqueue_path_trace(h, spans, e_begin_i, e_end_i);
-  // Drain all three streams whether or not the enqueue succeeded (a kernel fault surfaces here as well).
-  hipError_t s3 = hipSuccess;   // the chunk streams (forked from and joined to the NIF stream) first: a failed enqueue leaves nothing behind
-  for (hipStream_t cs : h->chunk_stream) { const hipError_t e = hipStreamSynchronize(cs); if (e != hipSuccess) s3 = e; }
-  const hipError_t s0 = hipStreamSynchronize(h->stream), s1 = hipStreamSynchronize(h->trace_stream),
-                   s2 = hipStreamSynchronize(h->acc_stream);
+  h->spans.clear();
+  const int rc = enqueue_path_trace(h, h->spans, h->e_begin_i, h->e_end_i);
+  // Success: everything the step queued -- the trace kernels (through the NIF stream's waits), the chunk streams (joined),
+  // the accumulate passes (e_acc), the counters' copy -- is ordered before the end of `stream`: ONE wait.  (Rounds 1-4
+  // synchronised five streams, copied the counters with a blocking hipMemcpy and read 3 event pairs per batch here: host
+  // time that a 1 M-path step of BASELINE configs[0] paid in full.)  Failure: drain every stream, whatever was queued.
+  hipError_t s0 = hipStreamSynchronize(h->stream), s1 = hipSuccess, s2 = hipSuccess, s3 = hipSuccess;
+  if (rc || s0 != hipSuccess) {
+    for (hipStream_t cs : h->chunk_stream) { const hipError_t e = hipStreamSynchronize(cs); if (e != hipSuccess) s3 = e; }
+    s1 = hipStreamSynchronize(h->trace_stream);
+    s2 = hipStreamSynchronize(h->acc_stream);
+    (void)hipStreamSynchronize(h->stream);   // (what joined it late is drained too)
+  }
   if (rc) return rc;   // h->error names the failing call
   for (hipError_t e : {s0, s1, s2, s3})
     if (e != hipSuccess) return fail(h, PT_ERR_HIP, std::string("path_trace: ") + hipGetErrorString(e));
   h->sample_cursor += h->samples_per_step;
-
-  unsigned long long counters[2] = {0, 0};
-  PT_HIP(hipMemcpy(counters, h->d_counters, sizeof(counters), hipMemcpyDeviceToHost));
-  h->stats.paths = (uint64_t)n * h->samples_per_step;
-  h->stats.segments = counters[0];
-  h->stats.escaped = counters[1];
-  for (const StageSpan& s : spans) {
-    float ms = 0.f;
-    PT_HIP(hipEventElapsedTime(&ms, h->events[s.a], h->events[s.b]));
-    if (s.kind == 0) h->stats.path_trace_ms += ms;
-    else if (s.kind == 1) h->stats.nif_ms += ms;
-    else h->stats.accumulate_ms += ms;
-  }
-  float total_ms = 0.f;
-  PT_HIP(hipEventElapsedTime(&total_ms, h->events[e_begin_i], h->events[e_end_i]));
-  h->stats.total_ms = total_ms;
+  h->stats.paths = (uint64_t)h->n_real * h->samples_per_step;   // padding items are not traced (pt_setup)
+  h->stats.segments = h->h_counters[0];
+  h->stats.escaped = h->h_counters[1];
+  h->spans_pending = true;
   return PT_OK;
 }
 
@@ -601,8 +624,9 @@ int pt_calibrate_nif(pt_handle h, uint32_t launches, double* ms_per_launch, uint
   if (!ms_per_launch || !evaluations || launches == 0) return fail(h, PT_ERR_INVALID_ARGUMENT, "pt_calibrate_nif: bad arguments");
   if (!h->nif_valid) return fail(h, PT_ERR_NOT_READY, "pt_upload_nif has not been called");
   const pt_context::BatchBuffers& B = h->bb[h->bb[1].last_paths > h->bb[0].last_paths ? 1 : 0];
-  if (B.last_paths == 0) return fail(h, PT_ERR_NOT_READY, "no path_trace with a NIF environment has run on this handle yet");
+  if (B.last_paths == 0) return fail(h, PT_ERR_NOT_READY, "no path_trace with a NIF environment has run on this handle since the last pt_upload_nif / pt_set_constant_env");
   PT_HIP(hipSetDevice(h->cfg.device));
+  if (int rc = resolve_stage_times(h)) return rc;   // two of the step's events are reused below
   PT_HIP(hipStreamSynchronize(h->stream));
   std::vector<uint32_t> counts(B.last_regions);
   PT_HIP(hipMemcpy(counts.data(), B.region_count, counts.size() * 4, hipMemcpyDeviceToHost));
@@ -637,6 +661,7 @@ int pt_calibrate_nif(pt_handle h, uint32_t launches, double* ms_per_launch, uint
 int pt_get_stats(pt_handle h, pt_stats* stats) {
   if (!h) return PT_ERR_INVALID_ARGUMENT;
   if (!stats) return fail(h, PT_ERR_INVALID_ARGUMENT, "null stats");
+  if (int rc = resolve_stage_times(h)) return rc;
   *stats = h->stats;
   return PT_OK;
 }
@@ -653,7 +678,10 @@ int pt_read_results(pt_handle h, pt_trace_record* work, size_t n, pt_stats* stat
     PT_HIP(hipMemcpyAsync(work, h->d_records, n * sizeof(pt_trace_record), hipMemcpyDeviceToHost, h->stream));
     PT_HIP(hipStreamSynchronize(h->stream));
   }
-  if (stats) *stats = h->stats;
+  if (stats) {
+    if (int rc = resolve_stage_times(h)) return rc;
+    *stats = h->stats;
+  }
   return PT_OK;
 }
 

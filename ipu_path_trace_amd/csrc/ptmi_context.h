@@ -59,7 +59,9 @@ struct pt_context {
   uint32_t capacity = 0;
   ptd::TraceRecordDev* d_records = nullptr;
   ptd::Accum acc{};
+  uint32_t n_real = 0;                       // work items that are not padding (u < width and v < height: AccumulatedImage.cpp:66)
   unsigned long long* d_counters = nullptr;  // [0] segments, [1] escaped
+  unsigned long long* h_counters = nullptr;  // the same in pinned host memory: copied on the stream at the end of a step (no blocking hipMemcpy)
 
   // batch buffers, double-buffered: the trace kernel of batch b+1 runs on `trace_stream` while the NIF
   // kernel of batch b (MFMA-bound) runs on `stream`
@@ -72,6 +74,9 @@ struct pt_context {
   // unchanged -- the 60-VGPR / 106-SGPR kernel is resident six-fold per CU, not eight-fold as
   // hipOccupancyMaxActiveBlocksPerMultiprocessor reports, so a larger grid runs its last workgroups on part of the chip.
   static constexpr int kTraceBlocksPerCu = 6;
+  // Bytes of batch buffers per path of batch capacity, both sets: per path plen 1 + rad 12; per queue slot (one per path,
+  // rounded up per region) q_* 24 + survivor note 16 + path state 48.
+  static constexpr uint64_t kBatchBytesPerPath = 2 * (1 + 12 + 24 + 16 + 48);
   uint32_t trace_blocks = 1536;
   struct BatchBuffers {
     float *q_u = nullptr, *q_v = nullptr, *q_tr = nullptr, *q_tg = nullptr, *q_tb = nullptr;
@@ -139,9 +144,14 @@ struct pt_context {
   unsigned long long* d_stamps = nullptr;   // profiling build: 256 phase stamps of the wide-NIF layer kernel
   int diag_fault_batch = -1;                // test build: batch whose NIF launch fails (pt_diag_inject_fault), -1 = none
 
-  // stats
+  // stats.  The per-stage times are read lazily (pt_get_stats / pt_read_results): 3 hipEventElapsedTime calls per batch are
+  // host time a step of a small image should not pay (BASELINE configs[0] is one millisecond of device work per step).
   pt_stats stats{};
   std::vector<hipEvent_t> events;
+  struct StageSpan { size_t a, b; int kind; };   // event pair around one stage of one batch: 0 trace, 1 NIF, 2 accumulate
+  std::vector<StageSpan> spans;
+  size_t e_begin_i = 0, e_end_i = 0;
+  bool spans_pending = false;
 
   // scratch for the standalone entry points
   void* d_scratch = nullptr;
@@ -167,14 +177,22 @@ struct pt_context {
 
 namespace {
 
+inline int hip_status(hipError_t e);
+
 #define PT_HIP(call)                                                                         \
   do {                                                                                       \
     hipError_t e_ = (call);                                                                  \
     if (e_ != hipSuccess) {                                                                  \
       h->error = std::string(#call) + ": " + hipGetErrorString(e_);                          \
-      return PT_ERR_HIP;                                                                     \
+      return hip_status(e_);                                                                 \
     }                                                                                        \
   } while (0)
+
+// A failed allocation is its own status (include/ptmi.h): the caller can retry with a smaller max_work_items.
+inline int hip_status(hipError_t e) {
+  if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); return PT_ERR_OUT_OF_MEMORY; }   // not sticky: clear it for the next call
+  return PT_ERR_HIP;
+}
 
 int fail(pt_handle h, int code, const std::string& msg) {
   h->error = msg;
@@ -248,6 +266,8 @@ void fill_trace_params(pt_handle h, ptd::TraceParams& P) {
   const float fov = host_hround(h->fov);        // field_of_view stream is half (PathTracerApp.cpp:591)
   P.width_f = w;
   P.height_f = hgt;
+  P.width = c.width;
+  P.height = c.height;
   P.tx = tanf(fov * 0.5f);                      // light::pixelToRay (INFERRED: DESIGN.md, camera model)
   P.ty = (hgt / w) * P.tx;
   P.aa_scale = host_hround(h->aa_scale);        // anti_alias_scale stream is half (:590)

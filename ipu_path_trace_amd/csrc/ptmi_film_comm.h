@@ -123,6 +123,31 @@ static void comm_release(pt_handle h) {
 
 extern "C" {
 
+int pt_runtime_info(char* buf, size_t n) {
+  if (!buf || n == 0) { g_create_error = "null buffer"; return PT_ERR_INVALID_ARGUMENT; }
+  buf[0] = 0;
+  auto object_of = [](const void* fn) -> std::string {   // the shared object that DEFINES an imported function
+    Dl_info di;
+    std::string path = (dladdr(fn, &di) && di.dli_fname) ? di.dli_fname : "";
+    if (!path.empty()) { char real[PATH_MAX]; if (realpath(path.c_str(), real)) path = real; }
+    std::string out;
+    for (char c : path) { if (c == '"' || c == '\\') out += '\\'; out += c; }
+    return out;
+  };
+  int rccl = 0, hip_rt = 0, hip_drv = 0;
+  (void)ncclGetVersion(&rccl);
+  (void)hipRuntimeGetVersion(&hip_rt);
+  (void)hipDriverGetVersion(&hip_drv);
+  (void)hipGetLastError();
+  const std::string s = "{\"librccl\": \"" + object_of(reinterpret_cast<const void*>(&ncclGetVersion)) + "\", \"libamdhip64\": \"" +
+                        object_of(reinterpret_cast<const void*>(&hipRuntimeGetVersion)) + "\", \"rccl_version\": " + std::to_string(rccl) +
+                        ", \"rccl_compiled\": " + std::to_string(NCCL_VERSION_CODE) + ", \"hip_runtime_version\": " + std::to_string(hip_rt) +
+                        ", \"hip_driver_version\": " + std::to_string(hip_drv) + "}";
+  if (s.size() + 1 > n) { g_create_error = "pt_runtime_info: buffer too small"; return PT_ERR_INVALID_ARGUMENT; }
+  memcpy(buf, s.c_str(), s.size() + 1);
+  return PT_OK;
+}
+
 int pt_comm_get_unique_id(void* id_out) {
   static_assert(sizeof(ncclUniqueId) == PT_COMM_ID_BYTES, "PT_COMM_ID_BYTES must match ncclUniqueId");
   if (!id_out) { g_create_error = "null id buffer"; return PT_ERR_INVALID_ARGUMENT; }
@@ -146,6 +171,24 @@ int pt_comm_abort(pt_handle h) {
   return PT_OK;
 }
 
+// The RCCL this process bound (librccl.so.1 by SONAME: PyTorch's copy if torch was loaded first, else ROCm's) may be older
+// than the headers this file was compiled against.  A non-blocking communicator needs ncclCommInitRankConfig (2.14); an
+// older config reader is handed a struct stamped with ITS version, so it never looks for fields it does not know.
+static int comm_make_config(ncclConfig_t& cfg, std::string& err) {
+  int rt = 0;
+  const ncclResult_t r = ncclGetVersion(&rt);
+  if (r != ncclSuccess) { err = std::string("ncclGetVersion: ") + ncclGetErrorString(r); return PT_ERR_COMM; }
+  if (rt < NCCL_VERSION(2, 14, 0)) {
+    err = "the RCCL bound to this process is version " + std::to_string(rt) + ": too old for non-blocking communicators (needs 2.14)";
+    return PT_ERR_COMM;
+  }
+  const ncclConfig_t init = NCCL_CONFIG_INITIALIZER;
+  cfg = init;
+  cfg.blocking = 0;
+  if (rt < NCCL_VERSION_CODE) cfg.version = (unsigned int)rt;
+  return PT_OK;
+}
+
 static int comm_local_buffers(pt_handle h) {
   if (!h->d_slot_check) PT_HIP(dev_alloc(&h->d_slot_check, 2));
   return PT_OK;
@@ -159,8 +202,8 @@ int pt_comm_init_rank(pt_handle h, const void* id_in, int rank, int world) {
   if (int rc = comm_local_buffers(h)) return rc;
   ncclUniqueId id;
   memcpy(&id, id_in, sizeof(id));
-  ncclConfig_t cfg = NCCL_CONFIG_INITIALIZER;
-  cfg.blocking = 0;
+  ncclConfig_t cfg;
+  if (int rc = comm_make_config(cfg, h->error)) return rc;
   h->comm_broken = false;
   h->comm_abort_req.store(false);
   h->comm_slot_agreed = 0;
@@ -196,8 +239,8 @@ int pt_comm_init_all(pt_handle* handles, int n) {
   }
   ncclUniqueId id;
   PT_NCCL(ncclGetUniqueId(&id));
-  ncclConfig_t cfg = NCCL_CONFIG_INITIALIZER;
-  cfg.blocking = 0;
+  ncclConfig_t cfg;
+  if (int rc = comm_make_config(cfg, h->error)) return rc;
   std::vector<ncclComm_t> comms(n, nullptr);
   auto abort_all = [&]() { for (auto c : comms) if (c) (void)ncclCommAbort(c); };
   // one process, several devices: the rank-wise initialisations form one group

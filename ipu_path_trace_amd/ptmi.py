@@ -19,13 +19,13 @@ AA_NORMAL, AA_UNIFORM, AA_TRUNCATED_NORMAL = 0, 1, 2
 SAMPLES_HALF, SAMPLES_FLOAT = 0, 1
 DTYPE_F16, DTYPE_F32 = 0, 1
 
-ABI_VERSION = 4          # PTMI_ABI_VERSION of include/ptmi.h this binding was written against
+ABI_VERSION = 5          # PTMI_ABI_VERSION of include/ptmi.h this binding was written against
 EXPORTS = ["pt_abi_version", "pt_create", "pt_destroy", "pt_last_error", "pt_upload_nif", "pt_set_constant_env",
            "pt_set_render_settings", "pt_setup", "pt_path_trace", "pt_read_results", "pt_get_stats",
            "pt_export_hdr_device", "pt_clear_accumulators", "pt_synchronize", "pt_nif_infer", "pt_trace_paths",
            "pt_comm_get_unique_id", "pt_comm_init_rank", "pt_comm_init_all", "pt_comm_info", "pt_comm_set_timeout", "pt_comm_abort",
            "pt_gather_hdr", "pt_film_accumulate", "pt_tile_costs_enable", "pt_tile_costs", "pt_film_seed",
-           "pt_nif_kernel_name", "pt_calibrate_nif"]
+           "pt_nif_kernel_name", "pt_calibrate_nif", "pt_runtime_info"]
 COMM_ID_BYTES = 128
 HDR_ACCUMULATORS, HDR_FILM = 0, 1
 
@@ -114,6 +114,7 @@ def load_library(diag=False):
     L.pt_trace_paths.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     L.pt_nif_kernel_name.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
     L.pt_calibrate_nif.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    L.pt_runtime_info.argtypes = [C.c_char_p, C.c_size_t]
     if diag:
         L.pt_diag_inject_fault.argtypes = [C.c_void_p, C.c_int32]
         L.pt_diag_stamps.argtypes = [C.c_void_p, C.c_void_p]
@@ -309,6 +310,17 @@ class Renderer:
         self._check(self._lib.pt_trace_paths(self.handle, u.ctypes.data, v.ctypes.data, s.ctypes.data, u.size,
                                              out.ctypes.data))
         return out
+
+
+def runtime_info(diag=False):
+    """Which librccl / libamdhip64 the library's imports are bound to in THIS process, and their versions (pt_runtime_info)."""
+    import json
+    lib = load_library(diag)
+    buf = C.create_string_buffer(2048)
+    rc = lib.pt_runtime_info(buf, len(buf))
+    if rc:
+        raise PtError(rc, lib.pt_last_error(None).decode())
+    return json.loads(buf.value.decode())
 
 
 def comm_unique_id():

@@ -906,8 +906,12 @@ int orc_render(const orc_config* cfg, const orc_nif* nif, orc_trace_record* rec,
         int ne = 0;
         for (size_t j = 0; j < cnt; ++j) {
           orc_trace_record* t = &rec[base + j];
-          sizes[j] = trace_records(cfg, t->u, t->v, sample, stacks[j], NULL);
           slot[j] = -1;
+          /* worklist padding (LoadBalancer.cpp:66-71: u = v = 65535; skipped by the film, AccumulatedImage.cpp:66) is not
+           * traced: the reference's tiles trace it and discard the result, this restatement and the HIP path skip it --
+           * pathLength + 0, no radiance, not counted in `paths`. */
+          if (t->u >= cfg->width || t->v >= cfg->height) { sizes[j] = 0; continue; }
+          sizes[j] = trace_records(cfg, t->u, t->v, sample, stacks[j], NULL);
           if (stacks[j][sizes[j] - 1].type == ORC_ESCAPED) {
             if (cfg->env_mode == ORC_ENV_NIF) {
               dir_to_uv(stacks[j][sizes[j] - 1].clr, cfg->azimuth_radians, &us[ne], &vs[ne]);
@@ -940,7 +944,11 @@ int orc_render(const orc_config* cfg, const orc_nif* nif, orc_trace_record* rec,
     free(stacks);
     if (nif) scratch_free(s);
   }
-  if (stats) { stats->paths = (uint64_t)n * n_samples; stats->segments = segs; stats->escaped = esc; }
+  if (stats) {
+    uint64_t real = 0;
+    for (size_t i = 0; i < n; ++i) real += rec[i].u < cfg->width && rec[i].v < cfg->height;
+    stats->paths = real * n_samples; stats->segments = segs; stats->escaped = esc;
+  }
   return 0;
 }
 

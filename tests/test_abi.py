@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol(ptmi_lib):
         assert hasattr(lib, n), "libptmi.so does not export %s" % n
     assert sorted(ptmi_lib.EXPORTS) == names
     from ipu_path_trace_amd import ptmi as _binding
-    assert lib.pt_abi_version() == _binding.ABI_VERSION == 4   # 2: communicator + pt_gather_hdr, PT_DTYPE_F32; 3: communicator deadlines + pt_comm_abort, pt_tile_costs; 4: pt_nif_kernel_name, pt_calibrate_nif
+    assert lib.pt_abi_version() == _binding.ABI_VERSION == 5   # 5: pt_runtime_info; 2: communicator + pt_gather_hdr, PT_DTYPE_F32; 3: communicator deadlines + pt_comm_abort, pt_tile_costs; 4: pt_nif_kernel_name, pt_calibrate_nif
 
 
 def test_struct_layouts_match_header(ptmi_lib):

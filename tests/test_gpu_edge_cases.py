@@ -376,3 +376,21 @@ def test_nif_calibration_and_kernel_name(oracle, ptmi_lib):
     assert "nif32_layer_kernel" in r.nif_kernel_name()
     r.close()
     r2.close()
+
+
+def test_out_of_memory_is_its_own_status(ptmi_lib):
+    """A worklist capacity the device cannot hold: pt_create reports PT_ERR_OUT_OF_MEMORY (-6, include/ptmi.h), frees what it
+    had allocated, and the next, sane pt_create works (the reference's counterpart: Poplar's graph compilation failing with
+    an out-of-memory report, src/ipu_utils.hpp:532-535)."""
+    with pytest.raises(ptmi_lib.PtError) as e:
+        ptmi_lib.Renderer(65535, 65535, max_work_items=1500000000)       # ~370 GB of worklist, queue and batch buffers
+    assert e.value.code == -6, (e.value.code, str(e.value))
+    assert "hipMalloc" in str(e.value) or "dev_alloc" in str(e.value)
+    r = ptmi_lib.Renderer(32, 32, max_path_length=4)
+    r.set_constant_env((1.0, 1.0, 1.0))
+    r.init_render_settings(samples_per_step=2)
+    rec = ptmi_lib.worklist(32, 32)
+    r.setup(rec)
+    r.path_trace()
+    assert r.read_results(rec).paths == 32 * 32 * 2
+    r.close()

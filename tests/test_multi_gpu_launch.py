@@ -90,7 +90,20 @@ def test_bench_rehearsal_of_c4_four_ranks_film_equals_one_rank(tmp_path):
 _LONE_RANK = textwrap.dedent("""
     import sys, time
     sys.path.insert(0, %r)
+    BINDING = %r
+    if BINDING == "no_torch":
+        sys.modules["torch"] = None          # `import torch` now raises ImportError: ptmi.load_library loads libptmi.so without it
+    elif BINDING == "torch_first":
+        import torch
     from ipu_path_trace_amd import ptmi
+    info = ptmi.runtime_info()
+    print("RUNTIME", info)
+    if BINDING == "no_torch":
+        assert "torch" not in sys.modules or sys.modules["torch"] is None
+        assert "/opt/rocm" in info["librccl"] and "/opt/rocm" in info["libamdhip64"], info
+        assert info["rccl_version"] == info["rccl_compiled"], info      # the RCCL libptmi.so was compiled against
+    elif BINDING == "torch_first":
+        assert "/torch/lib/" in info["librccl"] and "/torch/lib/" in info["libamdhip64"], info
     r = ptmi.Renderer(32, 32, max_path_length=4)
     r.comm_set_timeout(4000)
     uid = ptmi.comm_unique_id()
@@ -129,8 +142,69 @@ def test_a_rank_whose_peer_never_arrives_times_out_and_recovers(tmp_path):
     the communicator is aborted, PT_ERR_COMM comes back -- and the process is still alive and usable.  Run in a child
     with a hard limit so that a regression (a hang) fails this test instead of stalling the suite."""
     script = tmp_path / "lone_rank.py"
-    script.write_text(_LONE_RANK % ROOT)
+    script.write_text(_LONE_RANK % (ROOT, "default"))
     t = time.time()
     p = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=240, env=_clean_env(), cwd=ROOT)
     assert p.returncode == 0 and "LONE_RANK_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
     assert time.time() - t < 200
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("binding", ["torch_first", "no_torch"])
+def test_both_runtime_bindings_pass_the_rccl_deadline_and_gather_tests(tmp_path, binding):
+    """libptmi.so imports librccl.so.1 / libamdhip64.so.7 by SONAME, so a process that imported torch first runs the library
+    on the copies PyTorch ships (an older RCCL than the headers it was compiled against: pt_comm_init_rank stamps the config
+    with the running library's version), and a process without torch -- the C++ CLI ipu_trace, or this child with torch
+    hidden -- runs it on ROCm's own.  bench.py is the first kind at every N.  Both bindings must pass the same body: the
+    lone-rank deadline on a world-2 communicator, recovery, and the single-rank gather on a real non-blocking communicator;
+    pt_runtime_info says which is which."""
+    script = tmp_path / ("lone_rank_%s.py" % binding)
+    script.write_text(_LONE_RANK % (ROOT, binding))
+    p = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300, env=_clean_env(), cwd=ROOT)
+    assert p.returncode == 0 and "LONE_RANK_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
+    assert "RUNTIME" in p.stdout
+
+
+def _bench_line(args, timeout=900, **env):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout,
+                       env=_clean_env(**env), cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_takes_the_real_n_rank_branch_at_world_size_one(tmp_path):
+    """`bench.py --gpus 1 --dist`: everything an N-rank run does that one GPU can execute, with the REAL backend -- the child
+    started by spawn_ranks(1), init_process_group("nccl"), the ncclUniqueId broadcast, pt_comm_init_rank(id, 0, 1), the
+    all-reduced agreement on a CUDA tensor, the warm-up product gather, max over ranks on CUDA, calibrate-then-barrier.  The
+    film that went through the communicator equals the plain one-GPU film bit for bit, and the line names the product gather
+    and the runtime it ran on.  Second case: a damaged unique id -- every rank (the one there is) must agree on the fallback
+    to torch.distributed's gather, say so in the line, and still deliver the same film.
+    Reference: --ipus N runs as one command (src/main.cpp:17-19, src/PathTracerApp.cpp:205-252)."""
+    import numpy as np
+    common = ["--gpus", "1", "--steps", "2", "--warmup", "1", "--samples-per-step", "8", "--no-cpu-baseline", "--no-secondary",
+              "--width", "368", "--height", "272"]
+    plain = str(tmp_path / "plain.npy")
+    out = _bench_line(common + ["--dump-film", plain])
+    assert out["config"]["hdr_gather"] == "pt_gather_hdr of one tile (no communicator)"
+    assert "/torch/lib/" in out["runtime"]["librccl"] and out["runtime"]["rccl_version"] > 0
+
+    dist_film = str(tmp_path / "dist.npy")
+    out = _bench_line(common + ["--dist", "--dump-film", dist_film])
+    assert out["n_gpus"] == 1 and out["value"] > 0
+    assert out["config"]["hdr_gather"] == "pt_gather_hdr (RCCL inside libptmi.so)", out["config"]
+    assert out["runtime"]["torch_imported_first"] and "/torch/lib/" in out["runtime"]["librccl"]
+    assert "nif_alone" in out["roofline"]                                     # calibrate-then-barrier ran
+    assert np.load(dist_film).tobytes() == np.load(plain).tobytes()
+
+    env_film = str(tmp_path / "env.npy")
+    out = _bench_line(common + ["--dump-film", env_film], BENCH_FORCE_DIST="1")   # the environment switch does the same
+    assert out["config"]["hdr_gather"] == "pt_gather_hdr (RCCL inside libptmi.so)"
+    assert np.load(env_film).tobytes() == np.load(plain).tobytes()
+
+    fallback = str(tmp_path / "fallback.npy")
+    out = _bench_line(common + ["--dist", "--comm-fault", "corrupt-id", "--comm-timeout-ms", "8000", "--dump-film", fallback])
+    assert out["config"]["hdr_gather"].startswith("torch.distributed gather (pt_comm_init_rank failed"), out["config"]
+    assert np.load(fallback).tobytes() == np.load(plain).tobytes()
