@@ -3,22 +3,29 @@
 // ptmi_context.h, ptmi_nif_pack.h, ptmi_nif_launch.h, [the entry points in ptmi.hip], ptmi_film_comm.h.
 #pragma once
 
-extern "C" {
-
 // ---- multi-GPU film hand-off over RCCL --------------------------------------------------------------------------
 // The path shards over pixels with no exchange of ray data (reference: one NIF replica per IPU, "no inter-ipu exchange",
 // PathTracerApp.cpp:205-252; results only meet on the host film, AccumulatedImage.cpp:59-74).  The one exchange step is
 // this gather of HDR tiles to rank 0 at a save interval: every peer sends its tile straight to the root over its own
 // xGMI link (grouped ncclSend / ncclRecv -- never a ring), 12 B per work item.
 //
-// No call in here can block for ever.  Communicators are NON-BLOCKING (ncclConfig_t::blocking = 0): every RCCL call
-// returns at once, and its completion -- connection set-up with a peer included -- is polled with
-// ncclCommGetAsyncError against the handle's deadline (pt_comm_set_timeout, default 120 s); the device side is polled
-// with hipStreamQuery against the same deadline.  On expiry, on an asynchronous RCCL error, or when another thread asks
-// (pt_comm_abort) the communicator is aborted (ncclCommAbort ends the kernels still waiting for a peer), the stream is
-// drained, and the call returns PT_ERR_COMM; the handle then refuses further gathers until it is given a new communicator.
-// Every step that can fail locally (argument checks, allocations, the export kernel) runs BEFORE a rank enters the
-// exchange, so a rank that returns early never leaves its peers inside a collective it has half joined: they time out.
+// No call in here can block for ever -- whatever the RCCL underneath does.  Two mechanisms, because two RCCLs are in
+// play (pt_runtime_info says which one a process is bound to):
+//  (1) Communicators are asked to be NON-BLOCKING (ncclConfig_t::blocking = 0) and their progress is polled with
+//      ncclCommGetAsyncError / hipStreamQuery against the handle's deadline (pt_comm_set_timeout, default 120 s).  RCCL
+//      2.26.6 (the copy PyTorch ships, what bench.py runs on) honours that: every call returns at once.
+//  (2) RCCL 2.27.7 (ROCm 7.2's own, what ipu_trace runs on) does NOT for the calls that need a peer: measured on the GPU
+//      box (scripts/diag/rccl_nonblocking.cpp), ncclCommInitRankConfig with blocking = 0 stays inside the call for as long
+//      as a rank is missing (its bootstrap sits in a blocking accept()), and ncclCommAbort then blocks too (it joins that
+//      initialisation first).  So EVERY RCCL call that may need a peer -- set-up, the exchanges' enqueue, finalize, abort --
+//      runs on a helper thread (comm_start) and the caller waits for it against the deadline (comm_join).  A call that
+//      does not come back is ABANDONED: its thread is left behind (detached; whatever it was making is released by the
+//      thread itself if the call ever returns), the handle loses its communicator and reports PT_ERR_COMM.
+// On expiry, on an asynchronous RCCL error, or when another thread asks (pt_comm_abort) the communicator is aborted
+// (ncclCommAbort ends the kernels still waiting for a peer), the stream is drained (polled, never trusted), and the call
+// returns PT_ERR_COMM; the handle then refuses further gathers until it is given a new communicator.  Every step that can
+// fail locally (argument checks, allocations, the export kernel) runs BEFORE a rank enters the exchange, so a rank that
+// returns early never leaves its peers inside a collective it has half joined: they time out.
 
 #define PT_NCCL(call)                                                                        \
   do {                                                                                       \
@@ -36,21 +43,134 @@ static void comm_backoff(unsigned& spins) {
   else std::this_thread::sleep_for(std::chrono::microseconds(spins < 2000 ? 50 : 500));
 }
 
+static inline bool nccl_ok(ncclResult_t r) { return r == ncclSuccess || r == ncclInProgress; }
+
+// One RCCL call (or group of calls) on the handle's worker thread.  RUNNING -> DONE by the worker, RUNNING -> ABANDONED by
+// the waiter (one compare-exchange decides who owns the outcome); a worker that finds its job abandoned releases what it made.
+struct CommJob {
+  enum : int { RUNNING = 0, DONE = 1, ABANDONED = 2 };
+  std::atomic<int> state{RUNNING};
+  ncclResult_t result = ncclSuccess;
+  std::string failed_call;                 // which call of a group failed
+  std::vector<ncclComm_t> comms;           // set-up jobs: the communicators being made (written by RCCL as soon as it has one)
+};
+
+// The worker: ONE long-lived thread per handle makes all of the handle's RCCL calls.  Long-lived on purpose: with a
+// non-blocking communicator an RCCL call leaves an asynchronous job behind whose bookkeeping lives in the CALLING thread's
+// thread-local storage (group.cc), so the calling thread has to outlive the communicator -- a thread per call aborted the
+// process in the first gather.  A worker whose call never returns is dropped by the handle (the next call gets a new
+// worker); it parks or stays blocked until the process ends.  After an orderly ncclCommDestroy the worker is told to exit.
+struct CommWorker {
+  std::mutex m;
+  std::condition_variable cv;
+  std::deque<std::function<void()>> jobs;
+  bool quit = false;
+  static void loop(std::shared_ptr<CommWorker> self) {
+    for (;;) {
+      std::function<void()> f;
+      {
+        std::unique_lock<std::mutex> lk(self->m);
+        self->cv.wait(lk, [&] { return self->quit || !self->jobs.empty(); });
+        if (self->jobs.empty()) return;
+        f = std::move(self->jobs.front());
+        self->jobs.pop_front();
+      }
+      f();
+    }
+  }
+  void post(std::function<void()> f) {
+    { std::lock_guard<std::mutex> lk(m); jobs.push_back(std::move(f)); }
+    cv.notify_one();
+  }
+  void stop() {
+    { std::lock_guard<std::mutex> lk(m); quit = true; }
+    cv.notify_one();
+  }
+};
+
+static std::shared_ptr<CommWorker> comm_worker(pt_handle h) {
+  if (!h->comm_worker) {
+    h->comm_worker = std::make_shared<CommWorker>();
+    std::thread(CommWorker::loop, h->comm_worker).detach();
+  }
+  return h->comm_worker;
+}
+
+template <class F>
+static std::shared_ptr<CommJob> comm_start(pt_handle h, size_t n_comms, F fn) {
+  auto job = std::make_shared<CommJob>();
+  job->comms.assign(n_comms, nullptr);
+  const int device = h->cfg.device;
+  comm_worker(h)->post([job, device, fn]() mutable {
+    (void)hipSetDevice(device);
+    job->result = fn(*job);
+    int expected = CommJob::RUNNING;
+    if (!job->state.compare_exchange_strong(expected, CommJob::DONE))
+      for (ncclComm_t c : job->comms) if (c) (void)ncclCommAbort(c);   // nobody waits any more: release the late arrival
+  });
+  return job;
+}
+
+// Wait for a job against a deadline (and pt_comm_abort).  true: the job is DONE and its result is the caller's;
+// false: it was abandoned -- the worker owns whatever the call still makes, and the handle lets go of that worker.
+static bool comm_join(pt_handle h, CommJob& job, comm_clock::time_point deadline, bool heed_abort_request = true) {
+  unsigned spins = 0;
+  for (;;) {
+    if (job.state.load(std::memory_order_acquire) == CommJob::DONE) return true;
+    if ((heed_abort_request && h->comm_abort_req.load()) || comm_clock::now() > deadline) {
+      int expected = CommJob::RUNNING;
+      if (!job.state.compare_exchange_strong(expected, CommJob::ABANDONED)) return true;   // lost the race: it finished just now
+      h->comm_worker.reset();
+      return false;
+    }
+    comm_backoff(spins);
+  }
+}
+
+// ncclCommAbort, bounded: it is a blocking call too (see (2) above).  Returns whether the abort has completed; if not it
+// goes on in the background on the worker the handle has just let go of.
+constexpr int kAbortGraceMs = 3000;
+static bool comm_abort_bounded(pt_handle h, ncclComm_t comm) {
+  if (!comm) return true;
+  auto job = comm_start(h, 0, [comm](CommJob&) { return ncclCommAbort(comm); });
+  return comm_join(h, *job, comm_clock::now() + std::chrono::milliseconds(kAbortGraceMs), false);
+}
+
 // Abort the handle's communicator and leave the handle without one.  Kernels of this communicator still spinning on a
-// peer see the abort flag and exit, so the stream can be drained afterwards.
-static void comm_abort_now(pt_handle h) {
-  if (h->comm) (void)ncclCommAbort(h->comm);
+// peer see the abort flag and exit, so the stream can be drained afterwards.  Returns whether RCCL's abort completed.
+static bool comm_abort_now(pt_handle h) {
+  const bool finished = comm_abort_bounded(h, h->comm);
   h->comm = nullptr;
   h->comm_broken = true;
   h->comm_slot_agreed = 0;
   h->comm_abort_req.store(false);
+  return finished;
+}
+
+// Drain the handle's stream after an abort, without trusting it to drain: polled for the grace period.
+static bool comm_drain_stream(pt_handle h) {
+  const auto until = comm_clock::now() + std::chrono::milliseconds(kAbortGraceMs);
+  for (;;) {
+    const hipError_t e = hipStreamQuery(h->stream);
+    (void)hipGetLastError();
+    if (e != hipErrorNotReady) return true;   // idle (or faulted: the next call on the stream reports it)
+    if (comm_clock::now() > until) return false;
+    std::this_thread::sleep_for(std::chrono::milliseconds(1));
+  }
 }
 
 static int comm_fail(pt_handle h, const std::string& why) {
-  comm_abort_now(h);
-  (void)hipStreamSynchronize(h->stream);   // nothing of the aborted exchange is left running on the caller's buffers
+  const bool finished = comm_abort_now(h);
+  const bool idle = comm_drain_stream(h);   // nothing of the aborted exchange is left running on the caller's buffers
   h->error = why + " -- communicator aborted";
+  if (!finished) h->error += " (RCCL's own abort has not returned after " + std::to_string(kAbortGraceMs) + " ms: left to finish in the background)";
+  if (!idle) h->error += " (the handle's stream is still busy with the aborted exchange)";
   return PT_ERR_COMM;
+}
+
+static std::string comm_no_progress(pt_handle h, const char* what) {
+  if (h->comm_abort_req.load()) return std::string(what) + ": aborted by pt_comm_abort";
+  return std::string(what) + ": no progress within " + std::to_string(h->comm_timeout_ms) + " ms (a peer is missing or has failed)";
 }
 
 // Host side of a non-blocking RCCL call: wait until the communicator has left ncclInProgress.
@@ -62,9 +182,7 @@ static int comm_wait_host(pt_handle h, const char* what, comm_clock::time_point 
     if (q != ncclSuccess) return comm_fail(h, std::string(what) + ": ncclCommGetAsyncError: " + ncclGetErrorString(q));
     if (st == ncclSuccess) return PT_OK;
     if (st != ncclInProgress) return comm_fail(h, std::string(what) + ": " + ncclGetErrorString(st));
-    if (h->comm_abort_req.load()) return comm_fail(h, std::string(what) + ": aborted by pt_comm_abort");
-    if (comm_clock::now() > deadline)
-      return comm_fail(h, std::string(what) + ": no progress within " + std::to_string(h->comm_timeout_ms) + " ms (a peer is missing or has failed)");
+    if (h->comm_abort_req.load() || comm_clock::now() > deadline) return comm_fail(h, comm_no_progress(h, what));
     comm_backoff(spins);
   }
 }
@@ -78,7 +196,7 @@ static int comm_wait_stream(pt_handle h, const char* what, comm_clock::time_poin
     if (e == hipSuccess) return PT_OK;
     if (e != hipErrorNotReady) {
       const std::string msg = std::string(what) + ": " + hipGetErrorString(e);
-      comm_abort_now(h);
+      (void)comm_abort_now(h);
       h->error = msg;
       return PT_ERR_HIP;
     }
@@ -97,26 +215,42 @@ static int comm_wait_stream(pt_handle h, const char* what, comm_clock::time_poin
 static comm_clock::time_point comm_deadline(pt_handle h) {
   return comm_clock::now() + std::chrono::milliseconds(h->comm_timeout_ms);
 }
-}  // extern "C"
 
-// pt_destroy's half of the communicator's life.  With blocking = 0 ncclCommFinalize / ncclCommDestroy may return
-// ncclInProgress: flush what the communicator still has in flight and wait for it (bounded by the handle's deadline)
-// BEFORE the caller destroys the streams it ran on; a communicator that does not settle in time is aborted instead.
+// Enqueue an exchange on the handle's communicator and stream: `fn` (the RCCL calls; it returns the first failing call's
+// result and names it in job.failed_call) runs on a helper thread; then the host side and the device side are awaited.
+template <class F>
+static int comm_exchange(pt_handle h, const char* what, comm_clock::time_point deadline, F fn) {
+  auto job = comm_start(h, 0, fn);
+  if (!comm_join(h, *job, deadline)) return comm_fail(h, comm_no_progress(h, what) + "; the RCCL call is still blocked and was left behind");
+  if (!nccl_ok(job->result)) return comm_fail(h, std::string(what) + ": " + job->failed_call + ": " + ncclGetErrorString(job->result));
+  if (int rc = comm_wait_host(h, what, deadline)) return rc;     // peers connected, transfer queued on the stream
+  return comm_wait_stream(h, what, deadline);                    // transfer done (or the communicator aborted)
+}
+
+// pt_destroy's half of the communicator's life: flush what the communicator still has in flight (ncclCommFinalize, which
+// may return ncclInProgress or simply take its time), wait for it and destroy it -- all on a helper thread, bounded by the
+// handle's deadline, BEFORE the caller destroys the streams it ran on; a communicator that does not settle is aborted.
 static void comm_release(pt_handle h) {
   if (!h->comm) return;
   const auto deadline = comm_deadline(h);
-  ncclResult_t r = ncclCommFinalize(h->comm);
-  bool settled = (r == ncclSuccess);
-  unsigned spins = 0;
-  while (!settled && (r == ncclSuccess || r == ncclInProgress)) {
-    ncclResult_t st = ncclSuccess;
-    if (ncclCommGetAsyncError(h->comm, &st) != ncclSuccess || (st != ncclSuccess && st != ncclInProgress)) break;
-    if (st == ncclSuccess) { settled = true; break; }
-    if (h->comm_abort_req.load() || comm_clock::now() > deadline) break;
-    comm_backoff(spins);
-  }
-  if (settled) (void)ncclCommDestroy(h->comm);
-  else (void)ncclCommAbort(h->comm);
+  ncclComm_t comm = h->comm;
+  auto job = comm_start(h, 0, [comm, deadline](CommJob&) {
+    ncclResult_t r = ncclCommFinalize(comm);
+    unsigned spins = 0;
+    while (r == ncclInProgress || r == ncclSuccess) {
+      ncclResult_t st = ncclSuccess;
+      if (ncclCommGetAsyncError(comm, &st) != ncclSuccess) return ncclInternalError;
+      if (st == ncclSuccess) return ncclCommDestroy(comm);
+      if (st != ncclInProgress) return st;
+      if (comm_clock::now() > deadline) return ncclInProgress;
+      comm_backoff(spins);
+    }
+    return r;
+  });
+  const bool joined = comm_join(h, *job, deadline + std::chrono::milliseconds(500), false);
+  const bool destroyed = joined && job->result == ncclSuccess;
+  if (!destroyed) (void)comm_abort_bounded(h, comm);
+  else if (h->comm_worker) { h->comm_worker->stop(); h->comm_worker.reset(); }   // nothing of the communicator is left: the worker may go
   h->comm = nullptr;
   h->comm_slot_agreed = 0;
 }
@@ -208,14 +342,23 @@ int pt_comm_init_rank(pt_handle h, const void* id_in, int rank, int world) {
   h->comm_abort_req.store(false);
   h->comm_slot_agreed = 0;
   const auto deadline = comm_deadline(h);
-  ncclComm_t comm = nullptr;
-  const ncclResult_t r = ncclCommInitRankConfig(&comm, world, id, rank, &cfg);
-  if (r != ncclSuccess && r != ncclInProgress) {
-    if (comm) (void)ncclCommAbort(comm);
-    return fail(h, PT_ERR_COMM, std::string("ncclCommInitRankConfig: ") + ncclGetErrorString(r));
+  // a rank that never arrives ends here, not in a hang: whether RCCL returns at once (non-blocking honoured: the polled wait
+  // below sees the deadline) or stays inside the call until every rank has checked in (then comm_join does)
+  auto job = comm_start(h, 1, [id, rank, world, cfg](CommJob& j) mutable {
+    return ncclCommInitRankConfig(&j.comms[0], world, id, rank, &cfg);
+  });
+  if (!comm_join(h, *job, deadline)) {
+    h->comm_broken = true;
+    h->comm_abort_req.store(false);
+    return fail(h, PT_ERR_COMM, comm_no_progress(h, "communicator set-up") + "; ncclCommInitRankConfig is still blocked and was left behind -- communicator aborted");
+  }
+  ncclComm_t comm = job->comms[0];
+  if (!nccl_ok(job->result)) {
+    (void)comm_abort_bounded(h, comm);
+    return fail(h, PT_ERR_COMM, std::string("ncclCommInitRankConfig: ") + ncclGetErrorString(job->result));
   }
   h->comm = comm;
-  if (int rc = comm_wait_host(h, "communicator set-up", deadline)) return rc;   // a rank that never arrives ends here, not in a hang
+  if (int rc = comm_wait_host(h, "communicator set-up", deadline)) return rc;
   h->comm_rank = rank;
   h->comm_world = world;
   return PT_OK;
@@ -237,27 +380,30 @@ int pt_comm_init_all(pt_handle* handles, int n) {
     if (hipSetDevice(devs[i]) != hipSuccess) return fail(h, PT_ERR_HIP, "hipSetDevice failed for device " + std::to_string(devs[i]));
     if (int rc = comm_local_buffers(handles[i])) { h->error = handles[i]->error; return rc; }
   }
-  ncclUniqueId id;
-  PT_NCCL(ncclGetUniqueId(&id));
   ncclConfig_t cfg;
   if (int rc = comm_make_config(cfg, h->error)) return rc;
-  std::vector<ncclComm_t> comms(n, nullptr);
-  auto abort_all = [&]() { for (auto c : comms) if (c) (void)ncclCommAbort(c); };
-  // one process, several devices: the rank-wise initialisations form one group
-  PT_NCCL(ncclGroupStart());
-  for (int i = 0; i < n; ++i) {
-    ncclResult_t r = (hipSetDevice(devs[i]) == hipSuccess) ? ncclCommInitRankConfig(&comms[i], n, id, i, &cfg) : ncclUnhandledCudaError;
-    if (r != ncclSuccess && r != ncclInProgress) {
-      (void)ncclGroupEnd();
-      abort_all();
-      return fail(h, PT_ERR_COMM, std::string("ncclCommInitRankConfig: ") + ncclGetErrorString(r));
-    }
-  }
-  {
-    const ncclResult_t r = ncclGroupEnd();
-    if (r != ncclSuccess && r != ncclInProgress) { abort_all(); return fail(h, PT_ERR_COMM, std::string("ncclGroupEnd: ") + ncclGetErrorString(r)); }
-  }
   const auto deadline = comm_deadline(h);
+  // one process, several devices: the rank-wise initialisations form one group (on a helper thread, as every RCCL call
+  // that may wait for a peer; here the peers are the other members of the group)
+  auto job = comm_start(h, (size_t)n, [devs, n, cfg](CommJob& j) mutable {
+    ncclUniqueId id;
+    ncclResult_t r = ncclGetUniqueId(&id);
+    if (r != ncclSuccess) { j.failed_call = "ncclGetUniqueId"; return r; }
+    r = ncclGroupStart();
+    if (!nccl_ok(r)) { j.failed_call = "ncclGroupStart"; return r; }
+    for (int i = 0; i < n; ++i) {
+      r = (hipSetDevice(devs[i]) == hipSuccess) ? ncclCommInitRankConfig(&j.comms[i], n, id, i, &cfg) : ncclUnhandledCudaError;
+      if (!nccl_ok(r)) { j.failed_call = "ncclCommInitRankConfig"; (void)ncclGroupEnd(); return r; }
+    }
+    r = ncclGroupEnd();
+    if (!nccl_ok(r)) j.failed_call = "ncclGroupEnd";
+    return r;
+  });
+  if (!comm_join(h, *job, deadline))
+    return fail(h, PT_ERR_COMM, comm_no_progress(h, "communicator set-up") + "; the RCCL call is still blocked and was left behind");
+  std::vector<ncclComm_t> comms = job->comms;
+  auto abort_all = [&]() { for (int i = 0; i < n; ++i) (void)comm_abort_bounded(handles[i], comms[i]); };
+  if (!nccl_ok(job->result)) { abort_all(); return fail(h, PT_ERR_COMM, job->failed_call + ": " + ncclGetErrorString(job->result)); }
   unsigned spins = 0;
   for (int i = 0; i < n;) {
     ncclResult_t st = ncclSuccess;
@@ -385,12 +531,8 @@ int pt_gather_hdr(pt_handle h, int32_t source, size_t slot_items, float* root_ho
   const float* result = h->d_hdr_stage;
   if (exchange) {
     const auto deadline = comm_deadline(h);
-    // an RCCL call that fails outright leaves the communicator in an unknown state: abort it (the peers time out)
-#define PT_NCCL_X(call)                                                                                   \
-    do {                                                                                                  \
-      const ncclResult_t r_ = (call);                                                                     \
-      if (r_ != ncclSuccess && r_ != ncclInProgress) return comm_fail(h, std::string(#call) + ": " + ncclGetErrorString(r_)); \
-    } while (0)
+    ncclComm_t comm = h->comm;
+    hipStream_t stream = h->stream;
     // ---- the slot size must be the same on every rank (the root's receive counts are its own slot_items): checked
     // once per communicator and slot size with a max all-reduce of {slot, -slot}; every rank sees the same verdict.
     // Device -> host copies are only issued on an IDLE stream (after the polled wait): a copy into pageable host memory
@@ -400,31 +542,35 @@ int pt_gather_hdr(pt_handle h, int32_t source, size_t slot_items, float* root_ho
       long long seen[2] = {0, 0};
       PT_HIP(hipMemcpyAsync(h->d_slot_check, mine, sizeof(mine), hipMemcpyHostToDevice, h->stream));
       PT_HIP(hipStreamSynchronize(h->stream));   // local work only so far; `mine` may go out of scope
-      PT_NCCL_X(ncclAllReduce(h->d_slot_check, h->d_slot_check, 2, ncclInt64, ncclMax, h->comm, h->stream));
-      if (int rc = comm_wait_host(h, "slot-size agreement", deadline)) return rc;
-      if (int rc = comm_wait_stream(h, "slot-size agreement", deadline)) return rc;
+      long long* check = h->d_slot_check;
+      if (int rc = comm_exchange(h, "slot-size agreement", deadline, [comm, stream, check](CommJob& j) {
+            j.failed_call = "ncclAllReduce";
+            return ncclAllReduce(check, check, 2, ncclInt64, ncclMax, comm, stream);
+          })) return rc;
       PT_HIP(hipMemcpy(seen, h->d_slot_check, sizeof(seen), hipMemcpyDeviceToHost));
       if (seen[0] != -seen[1])
         return fail(h, PT_ERR_INVALID_ARGUMENT, "slot_items differs between the ranks of the communicator (" + std::to_string(-seen[1]) +
                                                     " .. " + std::to_string(seen[0]) + "); this rank passed " + std::to_string(slot_items));
       h->comm_slot_agreed = slot_items;
     }
-    // ---- the gather itself
+    // ---- the gather itself (an RCCL call that fails outright leaves the communicator in an unknown state: aborted, the peers time out)
+    float* stage = h->d_hdr_stage;
+    float* all = h->d_hdr_gather;
     if (root) {
       PT_HIP(hipMemcpyAsync(h->d_hdr_gather, h->d_hdr_stage, floats * 4, hipMemcpyDeviceToDevice, h->stream));
-      PT_NCCL_X(ncclGroupStart());
-      for (size_t r = 1; r < world; ++r) {
-        const ncclResult_t e = ncclRecv(h->d_hdr_gather + r * floats, floats, ncclFloat, (int)r, h->comm, h->stream);
-        if (e != ncclSuccess && e != ncclInProgress) { (void)ncclGroupEnd(); return comm_fail(h, std::string("ncclRecv: ") + ncclGetErrorString(e)); }
-      }
-      PT_NCCL_X(ncclGroupEnd());
       result = h->d_hdr_gather;
-    } else {
-      PT_NCCL_X(ncclSend(h->d_hdr_stage, floats, ncclFloat, 0, h->comm, h->stream));
     }
-#undef PT_NCCL_X
-    if (int rc = comm_wait_host(h, "HDR gather", deadline)) return rc;     // peers connected, transfer queued on the stream
-    if (int rc = comm_wait_stream(h, "HDR gather", deadline)) return rc;   // transfer done (or the communicator aborted)
+    if (int rc = comm_exchange(h, "HDR gather", deadline, [comm, stream, stage, all, floats, world, root](CommJob& j) {
+          if (!root) { j.failed_call = "ncclSend"; return ncclSend(stage, floats, ncclFloat, 0, comm, stream); }
+          ncclResult_t r = ncclGroupStart();
+          if (!nccl_ok(r)) { j.failed_call = "ncclGroupStart"; return r; }
+          for (size_t p = 1; p < world; ++p) {
+            r = ncclRecv(all + p * floats, floats, ncclFloat, (int)p, comm, stream);
+            if (!nccl_ok(r)) { j.failed_call = "ncclRecv"; (void)ncclGroupEnd(); return r; }
+          }
+          j.failed_call = "ncclGroupEnd";
+          return ncclGroupEnd();
+        })) return rc;
   } else {
     PT_HIP(hipStreamSynchronize(h->stream));
   }
