@@ -442,7 +442,9 @@ struct NifV3Geometry {
 };
 
 // DIAG (timing-only builds, results invalid): bit 0 = no ring sync / DMA, bit 1 = no LDS reads of A,
-// bit 2 = no epilogue arithmetic, bit 3 = no encode.  Bit 5 (valid results, profiling build): workgroup 0 stamps
+// bit 2 = no epilogue arithmetic, bit 3 = no encode, bit 6 = HALF the LDS reads of A in the hidden layers (one fragment
+// per pair of MFMAs, used twice: exactly the LDS traffic of an NB = 2 kernel -- two 32-sample tiles per wave sharing every
+// weight fragment -- with nothing else changed: the upper bound of what NB = 2 could buy, profiles/r05_nif_nb2.txt).  Bit 5 (valid results, profiling build): workgroup 0 stamps
 // s_memtime / s_memrealtime around its whole tile loop -> the in-kernel clock (MI355X_MICROARCH.md, DVFS give-back item 6).
 #ifdef PTMI_DIAG_BUILD
 __device__ unsigned long long g_nif_clock[2];   // shader cycles, 100 MHz ticks of the last stamped launch's workgroup 0
@@ -680,29 +682,32 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void nif_kernel_v3(const Nif
     auto tile_mma = [&](const uint4* wj, half8 (&src)[KS], bool concat, f32x16& acc, half8 (&A)[2][GR], bool preloaded,
                         const uint4* next, auto&& after_group) __attribute__((always_inline)) {
       acc = (f32x16)(0.0f);
+      constexpr int RD = (DIAG & 64) ? 1 : GR;   // fragments really read per group
       if (!preloaded) {
 #pragma unroll
-        for (int i = 0; i < GR; ++i) A[0][i] = (DIAG & 2) ? in[i % IS] : as_half8(wj[i * 64]);
+        for (int i = 0; i < RD; ++i) A[0][i] = (DIAG & 2) ? in[i % IS] : as_half8(wj[i * 64]);
       }
       auto group = [&](auto gc) __attribute__((always_inline)) {
         constexpr int g2 = decltype(gc)::value;
         if constexpr (g2 + 1 < NG) {
 #pragma unroll
-          for (int i = 0; i < GR; ++i)
+          for (int i = 0; i < RD; ++i)
             A[(g2 + 1) & 1][i] = (DIAG & 2) ? in[(g2 + i) % IS] : as_half8(wj[((g2 + 1) * GR + i) * 64]);
         } else if constexpr (NG % 2 == 0 && !(DIAG & 2)) {
           if (next) {
 #pragma unroll
-            for (int i = 0; i < GR; ++i) A[0][i] = as_half8(next[i * 64]);
+            for (int i = 0; i < RD; ++i) A[0][i] = as_half8(next[i * 64]);
           }
         }
         if constexpr (GR == 4)
           asm volatile("" : "+v"(A[g2 & 1][0]), "+v"(A[g2 & 1][1]), "+v"(A[g2 & 1][2]), "+v"(A[g2 & 1][3])::"memory");
+        else if constexpr (RD == 1)
+          asm volatile("" : "+v"(A[g2 & 1][0])::"memory");
         else
           asm volatile("" : "+v"(A[g2 & 1][0]), "+v"(A[g2 & 1][1])::"memory");
 #pragma unroll
         for (int i = 0; i < GR; ++i)
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[g2 & 1][i], src[g2 * GR + i], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[g2 & 1][i % RD], src[g2 * GR + i], acc, 0, 0, 0);
         // keep the scheduler from sinking this group's MFMAs below the last group's fragment wait
         if constexpr (g2 + 2 == NG) __builtin_amdgcn_sched_barrier(0);
         after_group(gc);

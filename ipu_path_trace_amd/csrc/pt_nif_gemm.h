@@ -8,7 +8,7 @@
 //
 // Round 3: the 16x16x32 MFMA shape.  On this chip an MFMA-dense loop is clock-limited by power, and the 16x16x32 shape
 // holds a higher clock than 32x32x16 at equal cycles per FLOP (MI355X_MICROARCH.md, "DVFS give-back" item 7); the
-// round-2 kernel (32x32x16, csrc/diag/pt_nif_gemm32.h, kept in the profiling build for the A/B) sat on that power line.
+// round-2 kernel (32x32x16; removed in round 5, numbers in profiles/r03_c5_ablation.txt) sat on that power line.
 // The phase structure is unchanged; what changed is the fragment contract:
 //
 //   weights      piece (s, f)   = A operand of k-step s (32 inputs), feature tile f (16 outputs): lane (r = lane & 15,

@@ -30,11 +30,6 @@
 #include "pt_nif.h"
 #include "pt_nif_gemm.h"
 #include "pt_nif_f32.h"
-#ifdef PTMI_DIAG_BUILD
-#include "diag/pt_nif_gemm32.h"
-#include "diag/pt_nif16.h"
-#include "diag/pt_nif_variants.h"
-#endif
 #include "pt_trace.h"
 
 #include "ptmi_context.h"
@@ -153,8 +148,13 @@ int pt_create(const pt_config* cfg, pt_handle* out) {
   PT_HIPC(hipStreamCreateWithPriority(&h->trace_stream, hipStreamNonBlocking, prio_least));
   PT_HIPC(hipStreamCreateWithPriority(&h->acc_stream, hipStreamNonBlocking, prio_least));
 #ifdef PTMI_DIAG_BUILD
-  // profiling build: PTMI_SERIAL=1 runs the trace kernels on the NIF stream (no overlap) to measure interference
-  if (getenv("PTMI_SERIAL")) { (void)hipStreamDestroy(h->trace_stream); h->trace_stream = h->stream; h->serial = true; }
+  // profiling build: PTMI_SERIAL=1 runs the trace and accumulate kernels on the NIF stream (no overlap at all): every
+  // stage's HIP-event time is then that kernel alone on the device
+  if (getenv("PTMI_SERIAL")) {
+    (void)hipStreamDestroy(h->trace_stream); h->trace_stream = h->stream;
+    (void)hipStreamDestroy(h->acc_stream); h->acc_stream = h->stream;
+    h->serial = true;
+  }
 #endif
 #undef PT_HIPC
   *out = h;
@@ -184,7 +184,7 @@ int pt_destroy(pt_handle h) {
   (void)hipFree(h->tiles.cost); (void)hipFree(h->d_tile_tmp);
   for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
   if (h->trace_stream && !h->serial) { (void)hipStreamSynchronize(h->trace_stream); (void)hipStreamDestroy(h->trace_stream); }
-  if (h->acc_stream) { (void)hipStreamSynchronize(h->acc_stream); (void)hipStreamDestroy(h->acc_stream); }
+  if (h->acc_stream && !h->serial) { (void)hipStreamSynchronize(h->acc_stream); (void)hipStreamDestroy(h->acc_stream); }
   for (int i = 0; i + 1 < pt_context::kChunkSets; ++i) {
     if (h->chunk_stream[i]) { (void)hipStreamSynchronize(h->chunk_stream[i]); (void)hipStreamDestroy(h->chunk_stream[i]); }
     if (h->chunk_join[i]) (void)hipEventDestroy(h->chunk_join[i]);
@@ -263,8 +263,6 @@ static int upload_nif_f32(pt_handle h, const pt_layer* layers, uint32_t n_layers
   h->nif_emb = (int)Ep;
   h->nif_f32 = true;
   h->nif_gemm = false;
-  h->nif_gemm32 = false;
-  h->nif_m16 = false;
   h->nif_flops = flops;
   h->nif_valid = true;
   h->env_const = false;
@@ -307,24 +305,11 @@ int pt_upload_nif(pt_handle h, const pt_layer* layers, uint32_t n_layers, uint32
   if (rc) return rc;
   std::vector<uint16_t> wpack, bpack;
   ptd::NifParams N;
-  bool m16 = false, gemm32 = false;
   std::vector<float> head_in;
   float head_bias[3] = {0, 0, 0};
   uint32_t head_piece_base = 0;
-#ifdef PTMI_DIAG_BUILD
-  // A/B switch of the profiling build: PTMI_GEMM_SHAPE=32 keeps a wide network on the round-2 32x32x16 layer kernels
-  if (const char* k = getenv("PTMI_GEMM_SHAPE")) gemm32 = plan.gemm && atoi(k) == 32;
-  // A/B switch of the profiling build: PTMI_NIF_KERNEL=v4 packs for the 16x16x32 kernel (pt_nif16.h).  Measured equal
-  // to v3 in NIF time within 1-2 %, but its 230 VGPRs leave no room for the trace kernel's waves beside it, so
-  // the step is 1.5 % slower end to end (profiles/r01_c_nif_ablation.txt); v3 stays the product kernel.
-  if (const char* k = getenv("PTMI_NIF_KERNEL")) m16 = strcmp(k, "v4") == 0 && plan.Hp == 320 && plan.Ep == 12 && n_layers <= 8;
-  rc = m16 ? pack_nif16(h, padded, plan.Ep, wpack, bpack, N)
-       : (plan.gemm && !gemm32) ? pack_nif_g16(h, padded, plan.Ep, wpack, bpack, N, head_in, head_bias, head_piece_base)
-                                : pack_nif(h, padded, plan.Ep, wpack, bpack, N);
-#else
   rc = plan.gemm ? pack_nif_g16(h, padded, plan.Ep, wpack, bpack, N, head_in, head_bias, head_piece_base)
                  : pack_nif(h, padded, plan.Ep, wpack, bpack, N);
-#endif
   if (rc) return rc;
   PT_HIP(hipSetDevice(h->cfg.device));
   PT_HIP(hipStreamSynchronize(h->stream));
@@ -386,8 +371,6 @@ int pt_upload_nif(pt_handle h, const pt_layer* layers, uint32_t n_layers, uint32
   h->nif_emb = (int)plan.Ep;
   h->nif_f32 = false;
   h->nif_gemm = plan.gemm;
-  h->nif_gemm32 = gemm32;
-  h->nif_m16 = m16;
   h->nif_flops = flops;
   h->nif_valid = true;
   h->env_const = false;
@@ -823,7 +806,7 @@ int pt_diag_comm_self_exchange(pt_handle h, size_t floats, int* out_ok) {
   return PT_OK;
 }
 
-// profiling build only: in-kernel clock of the last stamped fused-NIF launch (nif_kernel_v3 with DIAG bit 5, nif_kernel_v4):
+// profiling build only: in-kernel clock of the last stamped fused-NIF launch (nif_kernel_v3 with DIAG bit 5):
 // out2[0] = shader cycles, out2[1] = 100 MHz ticks of its workgroup 0
 int pt_diag_nif_clock(pt_handle h, unsigned long long* out2) {
   if (!h || !out2) return PT_ERR_INVALID_ARGUMENT;

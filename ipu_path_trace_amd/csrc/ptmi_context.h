@@ -110,7 +110,6 @@ struct pt_context {
   bool nif_valid = false;
   int nif_hidden = 0, nif_emb = 0;   // PADDED hidden width / embedding dimension the kernels are instantiated for
   bool nif_gemm = false;  // layer-by-layer path (pt_nif_gemm.h)
-  bool nif_gemm32 = false;   // profiling build: the round-2 32x32x16 layer kernels (diag/pt_nif_gemm32.h) for the A/B
   // float32 models (pt_nif_f32.h): padded row-major kernels and biases of all layers in one buffer, chunk buffers
   bool nif_f32 = false;
   struct F32Layer { size_t w_off, b_off; uint32_t k_act, k_in, ldw, relu, half_out, cast_half; };
@@ -123,7 +122,6 @@ struct pt_context {
   float4* d_head_in = nullptr;        // head weights of the Fourier-feature inputs [4][E], if the head concatenates them
   float head_bias[3] = {0, 0, 0};
   uint32_t head_piece_base = 0;
-  bool nif_m16 = false;   // weights packed for nif_kernel_v4 (16x16x32 MFMA) rather than the 32x32x16 kernels
   ptd::NifParams nif{};
   uint4* d_wpack = nullptr;
   uint4* d_bpack = nullptr;

@@ -5,20 +5,6 @@
 
 namespace {
 
-#ifdef PTMI_DIAG_BUILD
-template <int HID, int E, int WAVES, int TPS>
-void launch_nif_v4(pt_handle h, const ptd::NifParams& N, int blocks) {
-  using G = ptd::NifV4Geometry<HID, E, WAVES, TPS>;
-  static std::atomic<unsigned long long> attr_set{0};   // one bit per device; the host app drives devices from threads
-  if (!(attr_set.load(std::memory_order_relaxed) >> (h->cfg.device & 63) & 1ull)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ptd::nif_kernel_v4<HID, E, WAVES, TPS>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
-    attr_set.fetch_or(1ull << (h->cfg.device & 63), std::memory_order_relaxed);
-  }
-  hipLaunchKernelGGL((ptd::nif_kernel_v4<HID, E, WAVES, TPS>), dim3(blocks), dim3(64 * WAVES), G::LDS_BYTES, h->stream, N);
-}
-#endif
-
 // Dynamic-LDS opt-in of a kernel, once per device (one bit per device: the host app drives devices from threads).
 int set_dynamic_lds(pt_handle h, const void* fn, int bytes, std::atomic<unsigned long long>& done) {
   const unsigned long long bit = 1ull << (h->cfg.device & 63);
@@ -67,6 +53,9 @@ bool launch_nif_diag(pt_handle h, const ptd::NifParams& N, int blocks) {
       case 15: launch_nif_v3<HID, E, 8, 2, 15>(h, N, blocks); return true;
       case 16: launch_nif_v3<HID, E, 8, 2, 16>(h, N, blocks); return true;
       case 32: launch_nif_v3<HID, E, 8, 2, 32>(h, N, blocks); return true;
+      case 34: launch_nif_v3<HID, E, 8, 2, 34>(h, N, blocks); return true;   // no LDS reads of A + clock stamps
+      case 64: launch_nif_v3<HID, E, 8, 2, 64>(h, N, blocks); return true;   // half the LDS reads of A (the NB = 2 bound)
+      case 96: launch_nif_v3<HID, E, 8, 2, 96>(h, N, blocks); return true;   // ... + clock stamps
       default: break;
     }
   }
@@ -82,11 +71,10 @@ int launch_nif_t(pt_handle h, const ptd::NifParams& N, int blocks) {
   constexpr int TPS = ((HID / 32) % 2 == 0) ? 2 : 1;
 #ifdef PTMI_DIAG_BUILD
   if constexpr (HID == 320 && E == 12) {
-    if (h->nif_m16) { launch_nif_v4<HID, E, 8, 2>(h, N, blocks); return PT_OK; }
     if (launch_nif_diag<HID, E>(h, N, blocks)) return PT_OK;
-    // A/B switch of the profiling build: 1 = weights straight from L2, 2 = LDS ring with 4 waves x 64 samples
+    // A/B switch of the profiling build over the v2 ring kernel (product code, other template arguments): 2 = FOUR waves x
+    // 64 samples (NB = 2: one wave per SIMD, every weight fragment feeds two 32-sample tiles), 3 = eight waves x 32 samples
     const int variant = getenv("PTMI_NIF_VARIANT") ? atoi(getenv("PTMI_NIF_VARIANT")) : 0;
-    if (variant == 1) { hipLaunchKernelGGL((ptd::nif_kernel<HID, E, 2>), dim3(blocks), dim3(256), 0, h->stream, N); return PT_OK; }
     if (variant == 2) return launch_nif_v2<HID, E, 2, 4>(h, N, blocks);
     if (variant == 3) return launch_nif_v2<HID, E, 1, 8>(h, N, blocks);
   }
@@ -120,137 +108,6 @@ int launch_nif_e(pt_handle h, const ptd::NifParams& N, int blocks) {
   }
   return fail(h, PT_ERR_UNSUPPORTED_MODEL, "no register-resident NIF kernel for hidden width " + std::to_string(h->nif_hidden));
 }
-#endif
-
-#ifdef PTMI_DIAG_BUILD
-template <int HID, int E>
-int launch_nif_wide(pt_handle h, const ptd::NifParams& N, int blocks) {
-  constexpr int lds = (HID / 16) * 2 * 1024 + (ptd::kMaxRegions + 1 + 256) * 4;
-  static std::atomic<unsigned long long> attr_set{0};
-  if (int rc = set_dynamic_lds(h, reinterpret_cast<const void*>(&ptd::nif_wide_kernel<HID, E>), lds, attr_set)) return rc;
-  hipLaunchKernelGGL((ptd::nif_wide_kernel<HID, E>), dim3(blocks), dim3(256), lds, h->stream, N);
-  return PT_OK;
-}
-#endif
-
-#ifdef PTMI_DIAG_BUILD
-// ---- profiling build: the round-2 32x32x16 layer path (A/B baseline)
-template <int E>
-void launch_nifg32_encode(pt_handle h, const ptd::NifParams& N, uint32_t tile0, uint32_t chunk) {
-  hipLaunchKernelGGL((ptd::nifg_encode_kernel<E>), dim3((chunk + 3u) / 4u), dim3(256), 0, h->stream, N, h->d_tile_start, tile0, chunk,
-                     h->d_gemm_feat);
-}
-
-// Wide networks, one launch per layer over chunks of the queue (pt_nif_gemm.h).  The number of queue tiles is only
-// known on the device, so chunks are launched up to the queue's capacity and those past its end return at once.
-int launch_nif_gemm32(pt_handle h, const ptd::NifParams& N) {
-  const uint32_t H = (uint32_t)h->nif_hidden, KS = H / 16, IS = (uint32_t)h->nif_emb / 4, NT = H / 32, FB = NT / 8;
-  const uint32_t n_layers = N.n_layers, chunk = h->gemm_chunk;
-  if (!chunk) return fail(h, PT_ERR_NOT_READY, "wide-NIF buffers are not allocated");
-  if (FB == 0 || NT % 8u) return fail(h, PT_ERR_UNSUPPORTED_MODEL, "layer-by-layer NIF path needs a hidden width that is a multiple of 256");
-  static std::atomic<unsigned long long> attr_set{0};
-  if (int rc = set_dynamic_lds(h, reinterpret_cast<const void*>(&ptd::nifg_layer_kernel<0>), ptd::kGemmLdsBytes, attr_set)) return rc;
-#ifdef PTMI_DIAG_BUILD
-  // A/B switches of the profiling build, read per launch: PTMI_GEMM_KERNEL = v1 (round-1 interleaved kernel) | ld (ping-pong
-  // + loader waves); PTMI_GEMM_DIAG = timing-only ablation bits of the selected kernel
-  const char* gk = getenv("PTMI_GEMM_KERNEL");
-  const int variant = !gk ? 0 : (!strcmp(gk, "v1") ? 1 : (!strcmp(gk, "ld") ? 2 : 0));
-  const int gdiag = getenv("PTMI_GEMM_DIAG") ? atoi(getenv("PTMI_GEMM_DIAG")) : 0;
-  auto launch_layer = [&](const ptd::NifGemmParams& G, uint32_t grid) -> int {
-#define PT_LAYER(KERNEL, THREADS)                                                                                         \
-    do {                                                                                                                  \
-      PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize,      \
-                                 ptd::kGemmLdsBytes));                                                                    \
-      hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(THREADS), ptd::kGemmLdsBytes, h->stream, G);                            \
-      return PT_OK;                                                                                                       \
-    } while (0)
-    if (variant == 2) PT_LAYER(ptd::nifg_layer_ld_kernel<0>, 768);
-    if (variant == 1) switch (gdiag) {
-      case 1: PT_LAYER(ptd::nifg_layer_v1_kernel<1>, 512); case 2: PT_LAYER(ptd::nifg_layer_v1_kernel<2>, 512);
-      case 3: PT_LAYER(ptd::nifg_layer_v1_kernel<3>, 512); case 4: PT_LAYER(ptd::nifg_layer_v1_kernel<4>, 512);
-      case 7: PT_LAYER(ptd::nifg_layer_v1_kernel<7>, 512); case 8: PT_LAYER(ptd::nifg_layer_v1_kernel<8>, 512);
-      case 16: PT_LAYER(ptd::nifg_layer_v1_kernel<16>, 512); default: PT_LAYER(ptd::nifg_layer_v1_kernel<0>, 512);
-    }
-    switch (gdiag) {
-      case 1: PT_LAYER(ptd::nifg_layer_kernel<1>, 512); case 2: PT_LAYER(ptd::nifg_layer_kernel<2>, 512);
-      case 3: PT_LAYER(ptd::nifg_layer_kernel<3>, 512); case 4: PT_LAYER(ptd::nifg_layer_kernel<4>, 512);
-      case 8: PT_LAYER(ptd::nifg_layer_kernel<8>, 512); case 16: PT_LAYER(ptd::nifg_layer_kernel<16>, 512);
-      case 128: PT_LAYER(ptd::nifg_layer_kernel<128>, 512);   // two phases per stage (valid results)
-      case 64: case 192: {   // stamped builds, four / two phases per stage (valid results): the stamps of the LAST layer launch are read by pt_diag_stamps
-        ptd::NifGemmParams GS = G;
-        GS.stamps = h->d_stamps;
-        if (gdiag == 64) {
-          PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ptd::nifg_layer_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, ptd::kGemmLdsBytes));
-          hipLaunchKernelGGL(ptd::nifg_layer_kernel<64>, dim3(grid), dim3(512), ptd::kGemmLdsBytes, h->stream, GS);
-        } else {
-          PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ptd::nifg_layer_kernel<192>), hipFuncAttributeMaxDynamicSharedMemorySize, ptd::kGemmLdsBytes));
-          hipLaunchKernelGGL(ptd::nifg_layer_kernel<192>, dim3(grid), dim3(512), ptd::kGemmLdsBytes, h->stream, GS);
-        }
-        return PT_OK;
-      }
-      default: break;
-    }
-#undef PT_LAYER
-    hipLaunchKernelGGL(ptd::nifg_layer_kernel<0>, dim3(grid), dim3(512), ptd::kGemmLdsBytes, h->stream, G);
-    return PT_OK;
-  };
-#else
-  auto launch_layer = [&](const ptd::NifGemmParams& G, uint32_t grid) -> int {
-    hipLaunchKernelGGL(ptd::nifg_layer_kernel<0>, dim3(grid), dim3(512), ptd::kGemmLdsBytes, h->stream, G);
-    return PT_OK;
-  };
-#endif
-  hipLaunchKernelGGL(ptd::nifg_scan_kernel, dim3(1), dim3(256), 0, h->stream, N.region_count, N.n_regions, h->d_tile_start);
-  PT_HIP(hipGetLastError());
-  const uint64_t max_tiles = (uint64_t)N.n_regions * ((N.region_cap + 31u) / 32u);
-  uint32_t grid = ((uint32_t)h->n_cus / (8u * FB)) * 8u * FB;
-  if (grid == 0) grid = 8u * FB;
-  ptd::NifGemmParams G{};
-  G.wpack = N.wpack;
-  G.bpack = N.bpack;
-  G.feat = h->d_gemm_feat;
-  G.act_stride = KS;
-  G.feat_stride = IS;
-  G.total_tiles = h->d_tile_start + N.n_regions;
-  G.chunk_tiles = chunk;
-  for (uint64_t tile0 = 0; tile0 < max_tiles; tile0 += chunk) {
-    G.tile0 = (uint32_t)tile0;
-    switch (h->nif_emb) {
-      case 4: launch_nifg32_encode<4>(h, N, G.tile0, chunk); break;
-      case 8: launch_nifg32_encode<8>(h, N, G.tile0, chunk); break;
-      case 12: launch_nifg32_encode<12>(h, N, G.tile0, chunk); break;
-      case 16: launch_nifg32_encode<16>(h, N, G.tile0, chunk); break;
-      default: return fail(h, PT_ERR_UNSUPPORTED_MODEL, "unsupported embedding dimension");
-    }
-    PT_HIP(hipGetLastError());
-    for (uint32_t l = 0; l + 1 < n_layers; ++l) {
-      const bool concat = (N.concat_mask >> l) & 1u;
-      G.piece_base = N.piece_base[l];
-      G.bias_base = N.bias_base[l];
-      G.ks_act = l ? KS : 0u;
-      G.ks_in = (l == 0 || concat) ? IS : 0u;
-      G.relu = (N.relu_mask >> l) & 1u;
-      G.n_ftiles = NT;
-      G.act_in = h->d_gemm_act[(l + 1u) & 1u];
-      G.act_out = h->d_gemm_act[l & 1u];
-      if (int rc = launch_layer(G, grid)) return rc;
-      PT_HIP(hipGetLastError());
-    }
-    const uint32_t l = n_layers - 1;
-    G.piece_base = N.piece_base[l];
-    G.bias_base = N.bias_base[l];
-    G.ks_act = KS;
-    G.ks_in = ((N.concat_mask >> l) & 1u) ? IS : 0u;
-    G.relu = (N.relu_mask >> l) & 1u;
-    G.n_ftiles = 1;
-    G.act_in = h->d_gemm_act[(l + 1u) & 1u];
-    G.act_out = nullptr;
-    hipLaunchKernelGGL(ptd::nifg_head_kernel, dim3((chunk + 15u) / 16u), dim3(256), 0, h->stream, N, G, h->d_tile_start);
-    PT_HIP(hipGetLastError());
-  }
-  return PT_OK;
-}
-
 #endif
 
 // Fork the chunk streams off the NIF stream / join them back (pt_context::chunk_stream).
@@ -506,15 +363,6 @@ int launch_nif(pt_handle h, const ptd::NifParams& N, int blocks) {
   h->nif_kernel = "(profiling-build variant)";   // every product launcher below overwrites it with the kernel it dispatches
   if (h->nif_f32) return launch_nif_f32(h, N);
   if (h->nif_gemm) {
-#ifdef PTMI_DIAG_BUILD
-    // A/B switch of the profiling build: the fused 64-sample kernel with activations in LDS
-    static const bool fused = getenv("PTMI_NIF_WIDE") && !strcmp(getenv("PTMI_NIF_WIDE"), "fused");
-    if (fused && h->nif_emb == 12 && h->nif_gemm32) {
-      if (h->nif_hidden == 1024) return launch_nif_wide<1024, 12>(h, N, blocks);
-      if (h->nif_hidden == 512) return launch_nif_wide<512, 12>(h, N, blocks);
-    }
-    if (h->nif_gemm32) return launch_nif_gemm32(h, N);
-#endif
     return launch_nif_gemm(h, N);
   }
   switch (h->nif_emb) {

@@ -239,86 +239,5 @@ int pack_nif_g16(pt_handle h, const std::vector<HostLayer>& L, uint32_t E, std::
   return PT_OK;
 }
 
-#ifdef PTMI_DIAG_BUILD
-// The same network packed for nif_kernel_v4 (v_mfma_f32_16x16x32_f16, pt_nif16.h).  Piece (l, j, s, ft): lane
-// (r = lane & 15, qg = lane >> 4) holds W^T[32 j + 16 ft + r][k(qg, 0..7)] with
-//  * activation k-step s:  k = 32 s + (e < 4 ? 4 qg + e : 16 + 4 qg + (e - 4))      (accumulator-as-operand order)
-//  * input k-step s':      coordinate cd = qg & 1, frequency f = 4 (2 s' + (qg >> 1)) + (e & 3);
-//                          k = base + (e < 4 ? 0 : 2E) + cd E + f, or a zero weight where f >= E (padding slots)
-// Pieces of a layer are ordered (j, s, ft); the head has one 16-row tile, ordered (s).  Bias of a 32-feature tile:
-// [qg][8]: e < 4 -> feature 32 j + 4 qg + e, e >= 4 -> 32 j + 16 + 4 qg + (e - 4).
-int pack_nif16(pt_handle h, const std::vector<HostLayer>& L, uint32_t E, std::vector<uint16_t>& wpack,
-               std::vector<uint16_t>& bpack, ptd::NifParams& N) {
-  const uint32_t n = (uint32_t)L.size();
-  if (n < 2 || n > ptd::kMaxLayers) return fail(h, PT_ERR_UNSUPPORTED_MODEL, "NIF must have 2..16 dense layers");
-  if (E == 0 || E % 4) return fail(h, PT_ERR_UNSUPPORTED_MODEL, "embedding dimension must be a multiple of 4");
-  const uint32_t in_dim = 4 * E, H = L[0].cols;
-  if (L[0].rows != in_dim) return fail(h, PT_ERR_UNSUPPORTED_MODEL, "first layer must take the 4*embedding Fourier features");
-  if (H % 32) return fail(h, PT_ERR_UNSUPPORTED_MODEL, "hidden size must be a multiple of 32");
-  if (L[n - 1].cols != 3) return fail(h, PT_ERR_UNSUPPORTED_MODEL, "NIF head must have 3 outputs (BGR)");
-  memset(&N, 0, sizeof(N));
-  N.n_layers = n;
-  const uint32_t in_steps_all = (E / 4 + 1) / 2;
-  uint32_t piece = 0, btile = 0;
-  for (uint32_t l = 0; l < n; ++l) {
-    const HostLayer& Y = L[l];
-    const bool head = (l == n - 1);
-    if (!head && Y.cols != H) return fail(h, PT_ERR_UNSUPPORTED_MODEL, "all hidden layers must have the same width");
-    bool concat = false;
-    uint32_t act_steps = 0;
-    if (l == 0) {
-      if (Y.rows != in_dim) return fail(h, PT_ERR_UNSUPPORTED_MODEL, "bad first layer shape");
-    } else if (Y.rows == H) {
-      act_steps = H / 32;
-    } else if (Y.rows == H + in_dim) {  // NifModel.cpp:305-308: x = concat(x, input)
-      act_steps = H / 32;
-      concat = true;
-    } else {
-      return fail(h, PT_ERR_UNSUPPORTED_MODEL, "layer input width is neither hidden nor hidden+features");
-    }
-    const uint32_t in_steps = (l == 0 || concat) ? in_steps_all : 0;
-    const uint32_t ksteps = act_steps + in_steps;
-    const uint32_t ntiles = head ? 1u : H / 32;
-    const uint32_t nft = head ? 1u : 2u;
-    N.piece_base[l] = piece;
-    N.bias_base[l] = btile;
-    if (concat) N.concat_mask |= 1u << l;
-    if (Y.relu) N.relu_mask |= 1u << l;
-    if (!Y.bias.empty()) N.bias_mask |= 1u << l;
-    wpack.resize((size_t)(piece + ntiles * ksteps * nft) * 512, 0);
-    bpack.resize((size_t)(btile + ntiles) * 32, 0);
-    for (uint32_t j = 0; j < ntiles; ++j) {
-      for (uint32_t s = 0; s < ksteps; ++s)
-        for (uint32_t ft = 0; ft < nft; ++ft) {
-          uint16_t* dst = &wpack[(size_t)(piece + (j * ksteps + s) * nft + ft) * 512];
-          for (uint32_t lane = 0; lane < 64; ++lane) {
-            const uint32_t r = lane & 15, qg = lane >> 4, col = 32 * j + 16 * ft + r;
-            for (uint32_t e = 0; e < 8; ++e) {
-              uint32_t k;
-              bool zero = col >= Y.cols;
-              if (s < act_steps) {
-                k = 32 * s + (e < 4 ? 4 * qg + e : 16 + 4 * qg + (e - 4));
-              } else {
-                const uint32_t sp = s - act_steps, cd = qg & 1, f = 4 * (2 * sp + (qg >> 1)) + (e & 3);
-                if (f >= E) zero = true;
-                k = (concat ? H : 0) + (e < 4 ? 0 : 2 * E) + cd * E + f;
-              }
-              dst[lane * 8 + e] = zero ? (uint16_t)0 : Y.kernel[(size_t)k * Y.cols + col];
-            }
-          }
-        }
-      for (uint32_t qg = 0; qg < 4; ++qg)
-        for (uint32_t e = 0; e < 8; ++e) {
-          const uint32_t col = 32 * j + (e < 4 ? 4 * qg + e : 16 + 4 * qg + (e - 4));
-          bpack[(size_t)(btile + j) * 32 + qg * 8 + e] = (!Y.bias.empty() && col < Y.cols) ? Y.bias[col] : (uint16_t)0;
-        }
-    }
-    piece += ntiles * ksteps * nft;
-    btile += ntiles;
-  }
-  return PT_OK;
-}
-
-#endif
 
 }  // namespace

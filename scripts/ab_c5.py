@@ -1,7 +1,8 @@
-"""Same-process A/B of the wide-NIF layer path (BASELINE config C5: NIF 8 x 1024): the round-2 32x32x16 kernels
-(diag/pt_nif_gemm32.h, selected with PTMI_GEMM_SHAPE=32 while the weights are uploaded) against the 16x16x32 kernels with
-the fused head (pt_nif_gemm.h), interleaved round by round on one device (cdna_hip_programming.md section 5.4 rule 24).
-Loads libptmi_diag.so.  usage: python scripts/ab_c5.py [rounds] [spp] [name=ENV:VAL,...]   (extra variants of the 16 path)
+"""Same-process A/B of the wide-NIF layer path (BASELINE config C5: NIF 8 x 1024): the product's 16x16x32 kernels with the
+fused head (pt_nif_gemm.h) against variants of themselves (PTMI_GEMM_DIAG bits, PTMI_CHUNK_STREAMS, CHUNK sizes), interleaved
+round by round on one device (cdna_hip_programming.md section 5.4 rule 24).  The round-2 32x32x16 baseline kernels were
+removed in round 5 (their numbers: profiles/r03_c5_ablation.txt).
+Loads libptmi_diag.so.  usage: python scripts/ab_c5.py [rounds] [spp] [name=ENV:VAL,...]   (variants of the 16 path)
 Prints per variant the NIF TFLOP/s (escaped x FLOP / sum of NIF-stage HIP-event time) and Mpath-samples/s of every round."""
 import os
 import sys
@@ -24,24 +25,21 @@ W, H = 1104, 1000
 L = A.synthetic_nif(hidden=hidden, layer_count=layers)
 
 
-def make(shape32, chunk=None):
-    if shape32:
-        os.environ["PTMI_GEMM_SHAPE"] = "32"
+def make(chunk=None):
     if chunk:
         os.environ["PTMI_GEMM_CHUNK"] = str(chunk)
     r = ptmi.Renderer(W, H, max_path_length=8, diag=True)
     r.init_nif_weights(L, 12, A.URBAN_ALLEY_META["max"], A.folded_mean())
-    os.environ.pop("PTMI_GEMM_SHAPE", None)
     os.environ.pop("PTMI_GEMM_CHUNK", None)
     r.init_render_settings(samples_per_step=spp)
     r.setup(ptmi.worklist(W, H))
     return r
 
 
-variants = [("mfma32x32x16", make(True), {}), ("mfma16x16x32", make(False), {})]
+variants = [("mfma16x16x32", make(), {})]
 for n, kv in extra:   # CHUNK:<tiles> in a variant makes its own renderer (the chunk size is fixed when the weights are uploaded)
     chunk = kv.pop("CHUNK", None)
-    variants.append((n, make(False, int(chunk)) if chunk else variants[1][1], kv))
+    variants.append((n, make(int(chunk)) if chunk else variants[0][1], kv))
 keys = sorted({k for _, _, kv in variants for k in kv})
 res = {n: [] for n, _, _ in variants}
 for rd in range(rounds + 1):

@@ -1,6 +1,6 @@
 """Interleaved A/B of NIF kernel variants of the profiling build, in ONE process on one device (cdna_hip_programming.md
 section 5.4 rule 24).  usage (always loads libptmi_diag.so): python scripts/ab_nif.py [rounds] [spp] name=ENV:VAL ...
-e.g.  v3= v2w8=PTMI_NIF_VARIANT:3 v2w4x64=PTMI_NIF_VARIANT:2
+e.g.  v3= v2w8=PTMI_NIF_VARIANT:3 v2w4x64=PTMI_NIF_VARIANT:2 halfreads=PTMI_NIF_DIAG:64
 Prints per variant the NIF TFLOP/s (escaped x FLOP / sum of NIF-kernel HIP-event time) and Mpath-samples/s of every round."""
 import os
 import sys

@@ -1,5 +1,5 @@
-"""Same-process A/B of the trace kernel (profiling build): the round-2 one-phase kernel (PTMI_TRACE_KERNEL=v1) against the
-two-phase kernel, (a) on its own -- constant sky, so no NIF kernel runs beside it -- and (b) inside the C2 step (6x320 NIF).
+"""Same-process A/B of the trace kernel (profiling build): the round-3 kernel (PTMI_TRACE_KERNEL=opt0) and any variant named in
+AB_TRACE_EXTRA (diag/ptmi_trace_variants.h: opt1 opt2 pipe scenec fn3 rounds cut1 cut2) against the product kernel, (a) on its own -- constant sky, so no NIF kernel runs beside it -- and (b) inside the C2 step (6x320 NIF).
 usage: python scripts/ab_trace.py [rounds] [spp]"""
 import os
 import sys
@@ -26,11 +26,11 @@ def make(const_env):
 
 
 for what, r in (("trace stage alone (constant sky)", make(True)), ("C2 step (NIF 6x320 beside it)", make(False))):
-    res = {k: [] for k in ["v1", "two-phase"] + os.environ.get("AB_TRACE_EXTRA", "").split()}
+    res = {k: [] for k in ["opt0", "product"] + os.environ.get("AB_TRACE_EXTRA", "").split()}
     for rd in range(rounds + 1):
         for name in res:
             os.environ.pop("PTMI_TRACE_KERNEL", None)
-            if name != "two-phase":
+            if name != "product":
                 os.environ["PTMI_TRACE_KERNEL"] = name
             t = time.time()
             r.path_trace()

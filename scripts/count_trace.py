@@ -1,5 +1,5 @@
 import os, sys, ctypes as C
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ipu_path_trace_amd import ptmi
 W,H=1104,1000
 for depth in (8,16):

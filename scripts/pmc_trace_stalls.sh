@@ -1,16 +1,19 @@
 #!/bin/bash
-# usage: scripts/pmc_trace_stalls.sh <tag>   (GPU box): where the trace kernel's wave-cycles go -- three counter-only passes over
-# scripts/trace_bench.py 8 (constant sky: the kernel on its own).
+# usage: scripts/pmc_trace_stalls.sh <tag> [depth = 8]   (GPU box): where the trace kernel's wave-cycles go -- three counter-only
+# passes over scripts/trace_bench.py <depth> (constant sky: the kernel on its own).  The depth is recorded in <out>/depth, as
+# scripts/pmc_trace.sh does.
 set -e
 ROOT=$GRAFT_REPO_ROOT; OUT=$ROOT/gpurun_out/$1; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+DEPTH=${2:-8}
+echo $DEPTH > $OUT/depth
 A="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"
 B="SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_MISC SQ_INSTS_VALU SQ_INSTS_SALU"
 C="SQ_INST_CYCLES_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH SQ_IFETCH"
 i=0
 for set in "$A" "$B" "$C"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d $OUT/t_$i -o c -- python3 $ROOT/scripts/trace_bench.py 8 > $OUT/t_$i.log 2>&1 || echo "[pmc_trace_stalls] pass $i failed (a counter of this set may not exist)"
+  rocprofv3 --pmc $set --output-format csv -d $OUT/t_$i -o c -- python3 $ROOT/scripts/trace_bench.py $DEPTH > $OUT/t_$i.log 2>&1 || echo "[pmc_trace_stalls] pass $i failed (a counter of this set may not exist)"
   echo "[pmc_trace_stalls] pass $i done"
 done
 python3 - "$OUT" <<'PY'

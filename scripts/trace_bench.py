@@ -4,7 +4,7 @@ from ipu_path_trace_amd import ptmi
 W,H=1104,1000
 depth=int(sys.argv[1]) if len(sys.argv)>1 else 8
 spp=64
-r=ptmi.Renderer(W,H,max_path_length=depth)
+r=ptmi.Renderer(W,H,max_path_length=depth,diag=(len(sys.argv)>2 and sys.argv[2]=='diag'))   # 'diag': the profiling build (honours PTMI_SERIAL etc.)
 r.set_constant_env((1,1,1))
 r.init_render_settings(samples_per_step=spp)
 rec=ptmi.worklist(W,H); r.setup(rec)
