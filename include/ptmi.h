@@ -82,10 +82,13 @@ typedef struct pt_layer {
   uint32_t rows, cols;
   const void* kernel;
   const void* bias;
-  int32_t dtype;                 /* PT_DTYPE_F16 or PT_DTYPE_F32.  Every layer runs in the type of its own kernel, as the reference
-                                  * gives a matmul its kernel's type (NifModel.cpp:314): a model with any float32 layer takes the
-                                  * float path (fp32 matrix rate), where its binary16 layers round their sums and add their bias
-                                  * in half and read their input cast to half; an all-binary16 model takes the fp16 kernels */
+  int32_t dtype;                 /* PT_DTYPE_F16 or PT_DTYPE_F32.  A model ALL of whose layers share one type runs as the reference's
+                                  * does: the matmul, bias add and ReLU in that type (NifModel.cpp:314-325).  A model that MIXES the two
+                                  * is an EXTENSION of this library with cast points of its own: the reference ships no such model, never
+                                  * casts x between layers and would most likely refuse one at graph construction.  Here every layer runs
+                                  * in the type of its own kernel on the float path (fp32 matrix rate): a binary16 layer rounds its sum
+                                  * to half, adds its bias in half and reads its input cast to half (RNE).  No reference fixture exists
+                                  * for it: parity unpinned (checked against the oracle's restatement of the same rule only). */
   int32_t relu;                  /* activation == "relu" (NifModel.cpp:323-325) */
 } pt_layer;
 

@@ -195,11 +195,12 @@ int pt_destroy(pt_handle h) {
   return PT_OK;
 }
 
-// A model with float32 layers: the float path (pt_nif_f32.h).  Every layer runs in the type of ITS kernel, as the reference
-// gives a matmul its kernel's type (NifModel.cpp:314): a binary16 layer of a mixed model is widened exactly (fp16 -> fp32 is
-// lossless, and a product of two halves is exact in float), its sum is rounded to half and its bias added in half, and the
-// activations it reads are cast to half first -- the fp32 FMA chain in k order is then the same sum the fp16 kernels'
-// oracle forms.  Such a model runs at the fp32 matrix rate throughout.
+// A model with float32 layers: the float path (pt_nif_f32.h).  All layers float32: every matmul, bias add and ReLU in float, as
+// the reference gives a matmul its kernel's type (NifModel.cpp:314-325).  A model that MIXES float32 and binary16 layers is an
+// EXTENSION with cast points of this library's own (the reference ships no such model and never casts x between layers): a
+// binary16 layer is widened exactly (fp16 -> fp32 is lossless, and a product of two halves is exact in float), its sum is
+// rounded to half and its bias added in half, and the activations it reads are cast to half first -- the fp32 FMA chain in k
+// order is then the same sum the fp16 kernels' oracle forms.  Such a model runs at the fp32 matrix rate throughout.
 static int upload_nif_f32(pt_handle h, const pt_layer* layers, uint32_t n_layers, uint32_t embedding_dim, float max,
                           const float mean[3], int32_t log_tonemap) {
   std::vector<HostLayerF32> L(n_layers);

@@ -184,14 +184,16 @@ void NifModel::upload(pt_handle device) const {
     p.kernel = l.kernel.data.data();
     p.bias = l.hasBias() ? l.bias.data.data() : nullptr;
     p.relu = l.activationFunction == "relu";
-    // NifModel.cpp:58-60 accepts float16 and float32 layers and gives every matmul its kernel's type (:314): pt_upload_nif
-    // runs each layer in its own type (a model with any float32 layer takes the float path)
+    // NifModel.cpp:58-60 accepts float16 and float32 layers and gives every matmul its kernel's type (:314).  An all-float32
+    // model runs in float as the reference's would; a model that MIXES the types is an extension of this port (its casts
+    // between layers are the port's own: the reference ships no such model and has no cast there)
     if (l.kernel.type == "float16") p.dtype = PT_DTYPE_F16;
     else if (l.kernel.type == "float32") { p.dtype = PT_DTYPE_F32; converted += 1; }
     else throw std::runtime_error("Unsupported NIF weight type '" + l.kernel.type + "' (expected float16 or float32).");
     ls.push_back(p);
   }
-  if (converted) pt_log::info_("NIF {}: {} of {} layers are float32: the model runs on the float path (fp32 matrix rate), each layer in its own type", name, converted, ls.size());
+  if (converted == ls.size()) pt_log::info_("NIF {}: all {} layers are float32: the model runs on the float path (fp32 matrix rate)", name, ls.size());
+  else if (converted) pt_log::warn_("NIF {}: {} of {} layers are float32 and the rest float16: a MIXED model is an extension of this port (each layer in its own type, activations cast between them by rules of its own -- the reference has no such model and no fixture for it)", name, converted, ls.size());
   const auto& m = data->getMetaData();
   if (pt_upload_nif(device, ls.data(), (std::uint32_t)ls.size(), (std::uint32_t)m.embeddingDimension, m.max, m.mean.data(),
                     m.logToneMap ? 1 : 0))

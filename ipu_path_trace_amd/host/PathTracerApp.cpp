@@ -9,11 +9,13 @@
 #include <algorithm>
 #include <fstream>
 #include <limits>
+#include <memory>
 #include <stdexcept>
 #include <thread>
 
 #include "AsyncTask.hpp"
 #include "logging.hpp"
+#include "trace_ranges.hpp"
 
 /// Adjust samples per pixel to be a multiple of samples per step (PathTracerApp.cpp:19-27).
 std::size_t roundSamplesPerPixel(std::size_t samplesPerPixel, std::size_t samplesPerIpuStep) {
@@ -244,8 +246,10 @@ void PathTracerApp::execute() {
   const float radians = (degrees / 360.f) * (float)(2.0 * M_PI);          // PathTracerApp.cpp:584
 
   renderStartTime = std::chrono::steady_clock::now();
+  pt_log::debug_("Host-phase trace ranges: {}", pt_trace::api().push ? pt_trace::api().library : "no ROCTx library found (ranges are no-ops)");
 
   // programs init_nif_weights and init_render_settings (PathTracerApp.cpp:612-614)
+  auto initialisation = std::make_unique<pt_trace::Range>("initialisation");   // PathTracerApp.cpp:567-639
   for (std::size_t d = 0; d < devices.size(); ++d) {
     if (args.has("constant-env") && !args.str("constant-env").empty()) {
       float rgb[3] = {1, 1, 1};
@@ -260,6 +264,8 @@ void PathTracerApp::execute() {
           "init_render_settings");
   }
   initialiseState(imageWidth, imageHeight);
+  initialisation.reset();
+  pt_trace::Range rendering("rendering");                                       // PathTracerApp.cpp:640
 
   pt_log::info_("Render started");
   // Nothing but the film ever has to leave the devices -- load balancing included: the balancer gets per-tile path-length
@@ -335,14 +341,15 @@ void PathTracerApp::executeResidentFilm(std::uint32_t steps) {
   // the task first, while those buffers are still alive.
   AsyncTask hostProcessing;
   onEveryDevice("setup", [&](std::size_t d) {
+    pt_trace::Range r("setup");
     return pt_setup(devices[d], reinterpret_cast<const pt_trace_record*>(deviceWork[d].data()), slot);
   });
   const std::size_t nTiles = balanceTileCount(imageWidth, imageHeight);
   if (loadBalanceEnabled)
     onEveryDevice("tile costs", [&](std::size_t d) { return pt_tile_costs_enable(devices[d], kBalanceTile, kBalanceTile); });
   if (slot > itemsPerDevice)
-    // padding items (u = v = 65535) are traced like any other item, as in the reference (LoadBalancer.cpp:66-71); the film and
-    // the tile costs skip them, Samples/sec counts image pixels only, Rays/sec includes them
+    // padding items (u = v = 65535, LoadBalancer.cpp:66-71) are not traced (the reference's tiles trace
+    // them and discard the result); the film and the tile costs skip them, Samples/sec and Rays/sec count image pixels only
     pt_log::info_("Load balancing: {} of {} work items per device are padding ({}%): room for any deal of {} image tiles", slot - itemsPerDevice,
                   slot, 100.0 * (double)(slot - itemsPerDevice) / (double)slot, nTiles);
 
@@ -352,7 +359,11 @@ void PathTracerApp::executeResidentFilm(std::uint32_t steps) {
     // path_trace, then on the device what the host task does in the reference's loop: film += (b,g,r)/sampleCount and
     // clear the accumulators (PathTracerApp.cpp:717-745)
     onEveryDevice("Device step", [&](std::size_t d) {
-      return pt_path_trace(devices[d]) || pt_get_stats(devices[d], &stats[d]) || pt_film_accumulate(devices[d]);
+      int rc;
+      { pt_trace::Range r("ipu_render"); rc = pt_path_trace(devices[d]) || pt_get_stats(devices[d], &stats[d]); }   // PathTracerApp.cpp:688-699
+      if (rc) return rc;
+      pt_trace::Range r("accumulate_framebuffers");                                                                // :725-727, on the device
+      return pt_film_accumulate(devices[d]);
     });
     std::size_t totalRays = 0;
     for (auto& s : stats) totalRays += s.segments;    // what clearInactiveAccumulators sums (LoadBalancer.cpp:198-213)
@@ -361,10 +372,11 @@ void PathTracerApp::executeResidentFilm(std::uint32_t steps) {
     pt_log::debug_("Total ms per step: {}", stats[0].total_ms);
 
     if (step % saveInterval == 0 || step == steps) {
-      hostProcessing.waitForCompletion();   // the previous save still reads filmRecords
+      { pt_trace::Range r("wait_for_host"); hostProcessing.waitForCompletion(); }   // the previous save still reads filmRecords (:702-706)
       // the ONE exchange of the multi-GPU path: HDR tiles to device 0 over RCCL, then to the host film
       // (--host-gather, or logical devices sharing a GPU: no communicator, every device hands its own tile to the host)
       onEveryDevice("HDR gather", [&](std::size_t d) {
+        pt_trace::Range r("hdr_gather");
         if (hostGather) return pt_gather_hdr(devices[d], PT_HDR_FILM, slot, tiles.data() + d * slot * 3);
         return pt_gather_hdr(devices[d], PT_HDR_FILM, slot, d == 0 ? tiles.data() : nullptr);
       });
@@ -382,6 +394,7 @@ void PathTracerApp::executeResidentFilm(std::uint32_t steps) {
         // N3 without the worklist leaving the devices (LoadBalancer::allocateWorkByPathLength, LoadBalancer.cpp:141-192):
         // per-tile path-length sums from every device, tiles re-dealt by cost, and the film follows its pixels
         // (pt_film_seed), so every pixel's fp32 sum continues in step order: the image is bit-identical to the unbalanced one.
+        pt_trace::Range balancing("run_load_balancing");                                                           // :748-751
         pt_log::info_("Load balancing started ({} image tiles over {} device{})", nTiles, devices.size(), devices.size() > 1 ? "s" : "");
         std::vector<std::vector<std::uint64_t>> part(devices.size(), std::vector<std::uint64_t>(nTiles));
         onEveryDevice("tile costs", [&](std::size_t d) { return pt_tile_costs(devices[d], part[d].data(), nTiles); });
@@ -413,13 +426,16 @@ void PathTracerApp::executeResidentFilm(std::uint32_t steps) {
         pt_log::info_("Load balancing finished");
       }
       hostProcessing.run([&, step]() {
+        pt_trace::Range async("async_work");                                                                        // :718
         traceState->film.reset();
         traceState->film.accumulate(filmRecords);
+        pt_trace::Range save("save_images");                                                                        // :761
         traceState->film.saveImages(fileName, step, configExposure, configGamma);   // hdr / step, as ever
         pt_log::info_("Saved images at step {}", step);
       });
     }
 
+    pt_trace::Range logging("log_stats");                                                                           // :765
     auto loopEndTime = std::chrono::steady_clock::now();
     auto secs = std::chrono::duration<double>(loopEndTime - loopStartTime).count();
     const auto pixelSamplesPerStep = (double)imageWidth * imageHeight * samplesPerIpuStep;
@@ -470,6 +486,7 @@ void PathTracerApp::executeHostFilm(std::uint32_t steps) {
 
     // Do the simple thing and restart the entire render if any state changed (PathTracerApp.cpp:656-676):
     if (uiServer && uiServer->stateChanged()) {
+      pt_trace::Range r("ui_processing");                                     // PathTracerApp.cpp:653
       state = uiServer->consumeState();
       const auto status = processUserInput(state, imageWidth, imageHeight);
       // (the previous step's host task may still be sending to the client: join it before the server goes away -- the
@@ -497,7 +514,7 @@ void PathTracerApp::executeHostFilm(std::uint32_t steps) {
       }
     }
     // Render settings can only be updated on these steps (:678-686), server or no server:
-    if (step == 1 || step == sampleCountReversionStep) sendRenderSettings();
+    if (step == 1 || step == sampleCountReversionStep) { pt_trace::Range r("update_ipu_settings"); sendRenderSettings(); }
 
     // setup -> path_trace -> read_results on every device (PathTracerApp.cpp:692-694).  The worklist is
     // cut into equal contiguous slices, one per device, as tiles are cut over IPUs.
@@ -506,6 +523,7 @@ void PathTracerApp::executeHostFilm(std::uint32_t steps) {
     onEveryDevice("Device step", [&](std::size_t d) {
       auto* slice = reinterpret_cast<pt_trace_record*>(active.data() + d * itemsPerDevice);
       pt_handle h = devices[d];
+      pt_trace::Range r("ipu_render");                                        // :688-699
       return pt_setup(h, slice, itemsPerDevice) || pt_path_trace(h) || pt_read_results(h, slice, itemsPerDevice, &stats[d]);
     });
     pt_log::debug_("Path-Trace ms: {}", stats[0].path_trace_ms);
@@ -514,7 +532,7 @@ void PathTracerApp::executeHostFilm(std::uint32_t steps) {
     pt_log::debug_("Step {} took {} samples per pixel from sample index {}", step, stats[0].paths / itemsPerDevice, stats[0].first_sample);
 
     const auto deviceDone = std::chrono::steady_clock::now();
-    hostProcessing.waitForCompletion();    // join the previous async task before swapping (:703-708)
+    { pt_trace::Range r("wait_for_host"); hostProcessing.waitForCompletion(); }   // join the previous async task before swapping (:703-708)
     traceState->work.getWork().swap();
     pt_log::debug_("Device calls (setup + path_trace + read_results) wall ms: {}",
                    std::chrono::duration<double, std::milli>(deviceDone - loopStartTime).count());
@@ -523,19 +541,25 @@ void PathTracerApp::executeHostFilm(std::uint32_t steps) {
 
     // The work list and film are captured by pointer: user interaction may make them defunct while this runs (:717)
     hostProcessing.run([&, step, workPtr = &traceState->work, filmPtr = &traceState->film]() {
-      filmPtr->accumulate(workPtr->getWork().inactive());
+      pt_trace::Range async("async_work");                                    // :718
+      { pt_trace::Range r("accumulate_framebuffers"); filmPtr->accumulate(workPtr->getWork().inactive()); }   // :725-727
       if (uiServer) {
         const auto ui = uiServer->getState();
-        uiServer->sendPreviewImage(filmPtr->updateLdrImage(step, ui.exposure, ui.gamma));
+        {
+          pt_trace::Range r("tone_map");                                      // :732-734 (+ ui_encode_video: the preview is sent as text here)
+          uiServer->sendPreviewImage(filmPtr->updateLdrImage(step, ui.exposure, ui.gamma));
+        }
+        pt_trace::Range r("ui_send_events");                                  // :738
         uiServer->updateProgress((int)step, (int)steps);
       }
-      if (loadBalanceEnabled && step > 1) workPtr->allocateWorkByPathLength(ipuJobs);
-      totalRays = workPtr->clearInactiveAccumulators();
+      if (loadBalanceEnabled && step > 1) { pt_trace::Range r("run_load_balancing"); workPtr->allocateWorkByPathLength(ipuJobs); }   // :748-751
+      { pt_trace::Range r("clear_accumulators"); totalRays = workPtr->clearInactiveAccumulators(); }                                   // :753-755
       if (step % saveInterval == 0 || step == steps) {
         if (uiServer) {
           // with a UI attached the raw image is transmitted at the save interval instead of saved (:748-753)
           uiServer->startSendingRawImage(filmPtr->getHdrImage(), step);
         } else {
+          pt_trace::Range r("save_images");                                   // :761
           filmPtr->saveImages(fileName, step, state.exposure, state.gamma);
           pt_log::info_("Saved images at step {}", step);
         }

@@ -111,11 +111,14 @@ void writeTiff(const std::string& fileName, const std::uint8_t* bgr8, std::size_
   auto f = openForWriting(fileName);
   const auto rgb = toRgb(bgr8, width * height);
   std::vector<std::uint8_t> h;
-  h.push_back('I'); h.push_back('I'); put16le(h, 42); put32le(h, (std::uint32_t)(8 + rgb.size()));   // IFD behind the pixels
+  // the IFD goes behind the pixels, on a WORD boundary as TIFF 6.0 requires: one pad byte where width x height is odd
+  const std::uint32_t pad = (std::uint32_t)(rgb.size() & 1u), ifd = (std::uint32_t)(8 + rgb.size()) + pad;
+  h.push_back('I'); h.push_back('I'); put16le(h, 42); put32le(h, ifd);
   f.write((const char*)h.data(), 8);
   f.write((const char*)rgb.data(), (std::streamsize)rgb.size());
+  if (pad) f.put('\0');
   std::vector<std::uint8_t> d;
-  const std::uint32_t ifd = (std::uint32_t)(8 + rgb.size()), nEntries = 10, bitsAt = ifd + 2 + nEntries * 12 + 4;
+  const std::uint32_t nEntries = 10, bitsAt = ifd + 2 + nEntries * 12 + 4;
   auto entry = [&](std::uint32_t tag, std::uint32_t type, std::uint32_t count, std::uint32_t value) {
     put16le(d, tag); put16le(d, type); put32le(d, count);
     if (type == 3 && count == 1) { put16le(d, value); put16le(d, 0); } else put32le(d, value);

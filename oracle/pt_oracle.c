@@ -595,6 +595,45 @@ void orc_object_ids(uint32_t w, uint32_t h, float fov, int8_t* ids) {
   }
 }
 
+/* Object a pixel's central ray finally reaches when it is followed DETERMINISTICALLY through the specular objects: a mirror
+ * hit reflects (light::reflect), a glass hit refracts (light::refract with its Fresnel roulette forced to "refract": u = 1;
+ * total internal reflection still reflects), a diffuse hit or the environment ends the walk.  ids: 0..5 = the diffuse object
+ * reached, -1 = environment, -2 = still inside specular objects after max_bounces; bounces: specular interactions on the way.
+ * This is what the reference's images/example.png shows INSIDE its mirror and glass spheres -- the one piece of reference
+ * output in which reflect and refract are at work -- so tests/test_oracle_example_image.py can pin both INFERRED routines and
+ * the refractive index against it.  `ri` is a parameter for the test's negative controls (1 / 1.5 = eta inverted; 1.33);
+ * reflect_variant 1 is a DELIBERATELY WRONG reflection (mirrored about the surface: 2 (d.n) n - d) for the same purpose. */
+void orc_specular_ids(uint32_t w, uint32_t h, float fov, float ri, int reflect_variant, int max_bounces, int8_t* ids,
+                      uint8_t* bounces) {
+  scene_init();
+#pragma omp parallel for schedule(dynamic, 8)
+  for (long long r = 0; r < (long long)h; ++r) {
+    for (uint32_t c = 0; c < w; ++c) {
+      vec3 o = V(0.f, 0.f, 0.f);
+      vec3 d = vnorm(pixel_to_ray((float)c, (float)r, w, h, fov));
+      int id = -2, nb = 0;
+      for (int b = 0; b <= max_bounces; ++b) {
+        vec3 normal;
+        float t;
+        const int obj = scene_intersect(&o, d, &normal, &t);
+        if (obj < 0) { id = -1; break; }
+        const int type = g_scene[obj].type;
+        if (type == MAT_DIFFUSE) { id = obj; break; }
+        if (b == max_bounces) break;
+        if (type == MAT_SPECULAR) {
+          if (reflect_variant == 1) { float cost = vdot(d, normal); d = vnorm(vsub(vscale(normal, cost * 2.0f), d)); }
+          else d = reflect_dir(d, normal);
+        } else {
+          (void)refract_dir(&d, normal, ri, 1.0f);
+        }
+        nb += 1;
+      }
+      ids[(size_t)r * w + c] = (int8_t)id;
+      if (bounces) bounces[(size_t)r * w + c] = (uint8_t)nb;
+    }
+  }
+}
+
 /* ------------------------------------------------------------------ NIF */
 struct orc_nif {
   uint32_t n_layers;

@@ -151,6 +151,8 @@ void orc_aa_noise(const orc_config*, uint16_t u, uint16_t v, uint32_t sample_ind
 void orc_scene_object(int index, float centre[3], float* radius, float colour[3], int32_t* type);
 /* object index per pixel (central ray), -1 = environment */
 void orc_object_ids(uint32_t w, uint32_t h, float fov, int8_t* ids);
+void orc_specular_ids(uint32_t w, uint32_t h, float fov, float ri, int reflect_variant, int max_bounces, int8_t* ids,
+                      uint8_t* bounces);
 
 #ifdef __cplusplus
 }

@@ -165,6 +165,7 @@ def _bind(L):
         L.orc_aa_noise.argtypes = [C.POINTER(Config), C.c_uint16, C.c_uint16, C.c_uint32, C.c_void_p]
         L.orc_scene_object.argtypes = [C.c_int, C.c_void_p, fp, C.c_void_p, C.POINTER(C.c_int32)]
         L.orc_object_ids.argtypes = [C.c_uint32, C.c_uint32, C.c_float, C.c_void_p]
+        L.orc_specular_ids.argtypes = [C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_build_info.restype = C.c_char_p
         L.orc_max_threads.restype = C.c_int
     return L
@@ -274,6 +275,17 @@ def object_ids(width, height, fov_radians):
     out = np.empty((height, width), dtype=np.int8)
     lib().orc_object_ids(width, height, float(fov_radians), out.ctypes.data)
     return out
+
+
+def specular_ids(width, height, fov_radians, refractive_index=1.5, reflect_variant=0, max_bounces=8):
+    """(int8 [height, width] final object, uint8 [height, width] specular interactions): the central ray of each pixel followed
+    deterministically through mirror (reflect) and glass (refract) to the first diffuse object (0..5), the environment (-1) or the
+    bounce limit (-2).  reflect_variant 1 and refractive indices other than the scene's 1.5 are the tests' negative controls."""
+    ids = np.empty((height, width), dtype=np.int8)
+    nb = np.empty((height, width), dtype=np.uint8)
+    lib().orc_specular_ids(width, height, float(fov_radians), float(refractive_index), int(reflect_variant), int(max_bounces),
+                           ids.ctypes.data, nb.ctypes.data)
+    return ids, nb
 
 
 def philox(ctr, key):

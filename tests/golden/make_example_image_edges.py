@@ -6,7 +6,14 @@ the disc's rim.  Only these measurements (a few thousand pixel coordinates) are 
 Method (no oracle, no scene knowledge beyond where to look): Gaussian-smoothed RGB (sigma 1.5), Sobel gradients, non-maximum
 suppression along the gradient direction; for each object the edge pixels above the 80th percentile of gradient magnitude
 inside a generous search region -- an annulus 0.7..1.3 r0 around a centre and radius r0 EYEBALLED from the picture, or a box
-for the disc rim.  tests/test_oracle_example_image.py aligns the oracle's silhouettes to these points."""
+for the disc rim.  tests/test_oracle_example_image.py aligns the oracle's silhouettes to these points.
+
+Round 5 adds what the picture shows INSIDE its mirror and glass spheres (the only reference output in which light::reflect and
+light::refract are at work): (a) the strong edges inside a disc of 0.93 r0 around each of the two spheres (coordinates, as
+above) and (b) a one-bit "floor-like" classification of the pixels in each sphere's bounding box -- the disc floor is the only
+dark red-brown surface of the scene (R > 1.5 G and R > 1.5 B on the sigma-1 smoothed picture; sky is blue-purple, lights are
+yellow) -- bit-packed.  The test compares both with where the oracle's deterministic specular walk (orc_specular_ids) puts the
+reflected / refracted floor and spheres."""
 import os
 import sys
 
@@ -50,6 +57,19 @@ e = nms & region & (g > np.percentile(g[region], 80))
 ey, ex = np.nonzero(e)
 out["disc_rim"] = np.stack([ex, ey], 1).astype(np.int16)
 out["disc_rim_index"] = np.int32(5)
+# ---- round 5: the interiors of the mirror and the glass sphere
+sm1 = ndimage.gaussian_filter(im, (1.0, 1.0, 0))
+floor_like = (sm1[..., 0] > 1.5 * sm1[..., 1]) & (sm1[..., 0] > 1.5 * sm1[..., 2]) & (sm1[..., 0] > 20)
+for name in ("mirror", "glass"):
+    _, (cx, cy), r0 = SPHERES[name]
+    rr = np.hypot(xx - cx, yy - cy)
+    region = rr < 0.93 * r0
+    e = nms & region & (g > np.percentile(g[region], 70))
+    ey, ex = np.nonzero(e)
+    out[name + "_interior"] = np.stack([ex, ey], 1).astype(np.int16)
+    x0, x1, y0, y1 = max(cx - int(1.4 * r0), 0), min(cx + int(1.4 * r0), W), max(cy - int(1.4 * r0), 0), min(cy + int(1.4 * r0), H)
+    out[name + "_floor_box"] = np.array([x0, x1, y0, y1], np.int32)
+    out[name + "_floor_bits"] = np.packbits(floor_like[y0:y1, x0:x1])
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "example_image_edges.npz")
 np.savez_compressed(path, **out)
 print({k: (v.shape if hasattr(v, "shape") and v.ndim else int(v)) for k, v in out.items()}, os.path.getsize(path), "bytes")

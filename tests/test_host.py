@@ -216,6 +216,19 @@ def test_film_accumulate_tonemap_and_exr(host, tmp_path):
         img = np.asarray(Image.open(jp).convert("RGB")).astype(np.int32)
         err = np.abs(img[..., ::-1] - ldr2.astype(np.int32))
         assert img.shape == (h2, w2, 3) and err.max() <= 12 and err.mean() < 2.0, (name, err.max(), err.mean())
+    # TIFF 6.0 wants the IFD on a word boundary: an image with an ODD pixel count (40 x 27 x 3 bytes of strip is even; 3 x 3 is
+    # not) gets a pad byte behind its strip, and the header's IFD offset is even
+    w3 = h3 = 3
+    rec3 = np.zeros(w3 * h3, dtype=TRACE_DTYPE)
+    r3, c3 = np.divmod(np.arange(w3 * h3), w3)
+    rec3["u"], rec3["v"], rec3["r"], rec3["g"], rec3["b"], rec3["sampleCount"] = c3, r3, 0.1 * (1 + c3), 0.1 * (1 + r3), 0.3, 1
+    hdr3, ldr3 = np.zeros((h3, w3, 3), np.float32), np.zeros((h3, w3, 3), np.uint8)
+    odd = str(tmp_path / "odd.tif")
+    assert host.pth_film_roundtrip(rec3.ctypes.data, rec3.size, w3, h3, 1, 0.0, 2.2, odd.encode(), hdr3.ctypes.data, ldr3.ctypes.data) == 0
+    raw = open(odd, "rb").read()
+    ifd = int.from_bytes(raw[4:8], "little")
+    assert ifd % 2 == 0 and ifd == 8 + 27 + 1 and raw[8 + 27] == 0
+    assert np.array_equal(np.asarray(Image.open(odd).convert("RGB"))[..., ::-1], ldr3)
     assert host.pth_film_roundtrip(rec.ctypes.data, rec.size, w, h, steps, 0.5, 2.2, str(tmp_path / "a.webp").encode(), hdr.ctypes.data,
                                    ldr.ctypes.data) != 0
     np.testing.assert_allclose(back, exp / steps, rtol=1e-6)

@@ -112,3 +112,71 @@ def test_all_five_silhouettes_align_with_the_reference_image(oracle):
         assert peak > 1.8 * np.median(list(scores.values())), name
     # occlusion order as declared: the magenta sphere hides part of the mirror sphere, the mirror sphere hides the disc's far rim
     assert (ids[560:600, 400:410] != 1).all() and (ids[380:420, 520:560] == 1).all()
+
+
+def _floor_like(f, name):
+    """The fixture's one-bit "floor-like" classification of the picture inside a sphere's bounding box, as a full-size mask."""
+    x0, x1, y0, y1 = [int(v) for v in f[name + "_floor_box"]]
+    H, W = int(f["height"]), int(f["width"])
+    bits = np.unpackbits(f[name + "_floor_bits"])[: (y1 - y0) * (x1 - x0)].reshape(y1 - y0, x1 - x0).astype(bool)
+    full = np.zeros((H, W), dtype=bool)
+    full[y0:y1, x0:x1] = bits
+    return full
+
+
+def _interior_scores(oracle, f, name, index, fov, **variant):
+    """(IoU of the predicted and the pictured floor region, fraction of the predicted region boundaries that lie within
+    3 px of a strong picture edge) inside the silhouette of sphere `index`, for the oracle's deterministic specular walk."""
+    from scipy import ndimage
+    W, H = int(f["width"]), int(f["height"])
+    inside = ndimage.binary_erosion(oracle.object_ids(W, H, fov) == index, iterations=6)
+    ids, _ = oracle.specular_ids(W, H, fov, **variant)
+    predicted, pictured = (ids == 5) & inside, _floor_like(f, name) & inside
+    iou = float((predicted & pictured).sum()) / float((predicted | pictured).sum())
+    bd = np.zeros_like(inside)
+    bd[:-1, :] |= ids[:-1, :] != ids[1:, :]
+    bd[:, :-1] |= ids[:, :-1] != ids[:, 1:]
+    bd &= inside
+    edges = np.zeros_like(inside)
+    pts = f[name + "_interior"]
+    edges[pts[:, 1].astype(int), pts[:, 0].astype(int)] = True
+    near_edge = ndimage.distance_transform_edt(~edges) <= 3.0
+    return iou, (float(near_edge[bd].mean()) if bd.any() else 0.0)
+
+
+def test_reflect_and_refract_against_the_inside_of_the_mirror_and_glass_spheres(oracle):
+    """Pins the INFERRED light::reflect and light::refract (codelets.cpp:205-213) against the one piece of reference output
+    that shows them at work: what images/example.png shows INSIDE its mirror sphere (the reflected tan, magenta and glass
+    spheres and the reflected floor with its rim) and inside its glass sphere (the floor seen upside down through two
+    refractions).  The oracle follows every pixel's central ray deterministically through the specular objects
+    (orc_specular_ids, at the 81 degrees the silhouettes fitted) and must put the floor where the picture has its only
+    red-brown surface, and its region boundaries on the picture's edges.  Negative controls, scores measured when the fixture
+    was made (IoU of the floor region / predicted boundaries on picture edges):
+
+        mirror sphere   reflect as restated   0.54 / 0.61      reflection mirrored about the surface   0.07 / 0.13
+        glass sphere    eta = 1/1.5 entering  0.66             eta INVERTED                            0.16
+        glass sphere    n = 1.5 (the default) 0.66             n = 1.33                                0.71   (NOT discriminated)
+
+    So the picture pins the reflection formula and which way Snell's ratio goes, and it does NOT pin the refractive index:
+    the floor region prefers 1.33-1.45 over the 1.5 default by a margin (0.04 IoU) smaller than the classifier's noise, and the
+    edge score cannot arbitrate inside the glass (0.23 at 1.5, 0.59 at 1.33, but 0.53 for the INVERTED eta: the refracted
+    skyline's own edges decide it, not the floor's rim) -- the picture was rendered with options nobody recorded (882 x 720, another NIF; --refractive-index is a command-line option,
+    PathTracerApp.cpp:804).  Still unpinned after this test: the roulette comparison, the diffuse weight, the Fresnel
+    probability (what decides WHEN a ray refracts), the 1.15 gain's side -- radiance, not geometry."""
+    f = np.load(EDGES)
+    fov = np.radians(81.0)
+    good_iou, good_edges = _interior_scores(oracle, f, "mirror", 1, fov)
+    bad_iou, bad_edges = _interior_scores(oracle, f, "mirror", 1, fov, reflect_variant=1)
+    assert good_iou > 0.45 and good_edges > 0.5, (good_iou, good_edges)
+    assert bad_iou < 0.2 and bad_edges < 0.25, (bad_iou, bad_edges)           # the wrong reflection FAILS
+    assert good_iou > 4 * bad_iou and good_edges > 2 * bad_edges
+
+    glass_iou, _ = _interior_scores(oracle, f, "glass", 2, fov)
+    inverted_iou, _ = _interior_scores(oracle, f, "glass", 2, fov, refractive_index=1.0 / 1.5)
+    assert glass_iou > 0.55, glass_iou
+    assert inverted_iou < 0.3 and glass_iou > 3 * inverted_iou, (glass_iou, inverted_iou)   # eta inverted FAILS
+    # the mirror does not care about the index; the glass sphere does, weakly: recorded, not asserted as a pin
+    water_iou, _ = _interior_scores(oracle, f, "glass", 2, fov, refractive_index=1.33)
+    assert abs(water_iou - glass_iou) < 0.1, (water_iou, glass_iou)           # 1.33 and 1.5 are NOT told apart by this picture
+    dense_iou, _ = _interior_scores(oracle, f, "glass", 2, fov, refractive_index=2.0)
+    assert dense_iou < glass_iou                                              # ... but the index is not free either
