@@ -22,3 +22,6 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o c -- $SHORT 
 echo "[profile_round] WRITE_SIZE done"
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc_mfma -o c -- $SHORT > $OUT/pmc_mfma.log 2>&1
 echo "[profile_round] MFMA counters done"
+python3 $ROOT/scripts/summarize_profile.py $TAG $OUT/summary > $OUT/summary.log 2>&1 && echo "[profile_round] summarised into $OUT/summary"
+rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_mfma   # raw per-dispatch counter CSVs: far beyond what gpurun copies back
+find $OUT/trace -type f ! -name "*kernel_stats.csv" -delete

@@ -1,7 +1,9 @@
 """Turn gpurun_out/<tag>/ (scripts/profile_round.sh) into the summaries committed under profiles/.
 
-usage: python scripts/summarize_profile.py <tag>
-Writes profiles/<tag>_bench.json, <tag>_kernel_stats.csv, <tag>_pmc.json.  HBM bytes follow MI355X_MICROARCH.md's
+usage: python scripts/summarize_profile.py <tag> [destination = profiles/]
+Writes <destination>/<tag>_bench.json, <tag>_kernel_stats.csv, <tag>_pmc.json.  scripts/profile_round.sh runs it ON THE GPU BOX
+with gpurun_out/<tag>/summary as destination and then deletes the raw counter CSVs (tens of MB per pass; gpurun copies back
+at most 64 MiB): commit the summary files under profiles/.  HBM bytes follow MI355X_MICROARCH.md's
 HBM/rocprofv3 section: FETCH_SIZE and WRITE_SIZE are KiB, collected in separate passes; on gfx950 FETCH_SIZE reports
 half the bytes of wide coalesced reads, so read bytes = 2 x FETCH_SIZE x 1024.
 """
@@ -34,7 +36,8 @@ def median_of_full(vals):
 def main():
     tag = sys.argv[1]
     src = os.path.join(ROOT, "gpurun_out", tag)
-    dst = os.path.join(ROOT, "profiles")
+    dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles")
+    os.makedirs(dst, exist_ok=True)
     bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
     stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
     if stats:
