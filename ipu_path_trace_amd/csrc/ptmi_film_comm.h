@@ -231,7 +231,10 @@ static int comm_exchange(pt_handle h, const char* what, comm_clock::time_point d
 // may return ncclInProgress or simply take its time), wait for it and destroy it -- all on a helper thread, bounded by the
 // handle's deadline, BEFORE the caller destroys the streams it ran on; a communicator that does not settle is aborted.
 static void comm_release(pt_handle h) {
-  if (!h->comm) return;
+  if (!h->comm) {   // no communicator alive (never made, or aborted to completion): a parked worker has nothing left to keep valid
+    if (h->comm_worker) { h->comm_worker->stop(); h->comm_worker.reset(); }
+    return;
+  }
   const auto deadline = comm_deadline(h);
   ncclComm_t comm = h->comm;
   auto job = comm_start(h, 0, [comm, deadline](CommJob&) {

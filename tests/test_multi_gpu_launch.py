@@ -40,6 +40,23 @@ def test_bench_spawns_its_own_ranks_and_relays_their_failure_without_a_gpu():
     assert "launch with torch.distributed.run" not in p.stderr
 
 
+def test_bench_dist_switch_spawns_a_rank_even_for_one_gpu_without_a_gpu():
+    """`--gpus 1 --dist` (and BENCH_FORCE_DIST=1) must go through spawn_ranks(1): here, without a GPU, the one child rank refuses
+    to run and the parent relays its exit code; plain `--gpus 1` refuses in-process.  (On a GPU box:
+    test_bench_takes_the_real_n_rank_branch_at_world_size_one.)"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by test_bench_takes_the_real_n_rank_branch_at_world_size_one")
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--samples-per-step", "1",
+            "--no-cpu-baseline", "--no-secondary"]
+    for extra, env in ((["--dist"], {}), ([], {"BENCH_FORCE_DIST": "1"})):
+        p = subprocess.run(base + extra, capture_output=True, text=True, timeout=300, env=_clean_env(**env), cwd=ROOT)
+        assert p.returncode != 0 and "needs an MI355X" in p.stderr, p.stderr[-1500:]
+        assert "torch.distributed" in p.stderr or "ChildFailedError" in p.stderr or "elastic" in p.stderr, p.stderr[-1500:]   # it WAS a launched rank
+    p = subprocess.run(base, capture_output=True, text=True, timeout=300, env=_clean_env(), cwd=ROOT)
+    assert p.returncode != 0 and "needs an MI355X" in p.stderr and "elastic" not in p.stderr
+
+
 @pytest.mark.gpu
 def test_bench_two_ranks_started_by_bench_itself():
     """`python bench.py --gpus 2` with WORLD_SIZE unset: rc 0 and a bench line for two ranks whose film covers the image."""
