@@ -30,7 +30,9 @@ typedef struct pt_context* pt_handle;
 
 /* Wire format of the `trace_buffer` stream: src/codelets/TraceRecord.hpp:7-19
  * (20 bytes; offsets 0/2/4/8/12/16/18).  Padding items carry u = v = 65535
- * (src/LoadBalancer.cpp:66-71) and are traced like any other item. */
+ * (src/LoadBalancer.cpp:66-71).  The reference's tiles trace them like any other item and the film skips them
+ * (src/AccumulatedImage.cpp:66); here an item with u >= width or v >= height is NOT traced: its sampleCount advances, its
+ * r, g, b and pathLength do not, and pt_stats counts image pixels only. */
 typedef struct pt_trace_record {
   uint16_t u, v;
   float r, g, b;
@@ -95,7 +97,7 @@ typedef struct pt_layer {
 /* Replaces the three cycle-count streams (PathTracerApp.cpp:598-603) with per-stage device
  * times from HIP events, plus the counters the roofline accounting needs. */
 typedef struct pt_stats {
-  uint64_t paths;                /* path-samples traced by the last path_trace */
+  uint64_t paths;                /* path-samples traced by the last path_trace (work items that are not padding x samples) */
   uint64_t segments;             /* sum of pathLength (LoadBalancer.cpp:198-213 "totalRays") */
   uint64_t escaped;              /* paths that reached the environment light = NIF evaluations */
   uint64_t nif_flops_per_sample; /* NifModel::analyseModel formula (NifModel.cpp:129-133) */
