@@ -502,6 +502,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void nif_kernel_v3(const Nif
   // DIAG bit 4 (16): static priority for the second-dispatched half of the workgroup, the arbitration loser of every SIMD
   // pair (MI355X_MICROARCH.md, "Two waves per SIMD", item 4)
   if constexpr (DIAG & 16) { if (wave >= WAVES / 2) __builtin_amdgcn_s_setprio(1); }
+  // DIAG bit 7 (128, valid results): every wave of the kernel at raised priority for its whole life, so that the trace kernel's
+  // waves co-resident on the SIMD (priority 0) only get the issue slots the MFMA waves leave (round-5 A/B: profiles/r05_nif_nb2.txt, section 4)
+  if constexpr (DIAG & 128) __builtin_amdgcn_s_setprio(2);
 
   // Slab stream of one pass: layer 0 in groups of T0 tiles, hidden layers in groups of TPS, head alone.
   const uint32_t n_layers = P.n_layers;

@@ -56,6 +56,7 @@ bool launch_nif_diag(pt_handle h, const ptd::NifParams& N, int blocks) {
       case 34: launch_nif_v3<HID, E, 8, 2, 34>(h, N, blocks); return true;   // no LDS reads of A + clock stamps
       case 64: launch_nif_v3<HID, E, 8, 2, 64>(h, N, blocks); return true;   // half the LDS reads of A (the NB = 2 bound)
       case 96: launch_nif_v3<HID, E, 8, 2, 96>(h, N, blocks); return true;   // ... + clock stamps
+      case 128: launch_nif_v3<HID, E, 8, 2, 128>(h, N, blocks); return true;  // every wave at raised priority (valid results)
       default: break;
     }
   }
