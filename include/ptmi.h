@@ -203,19 +203,21 @@ int pt_calibrate_nif(pt_handle h, uint32_t launches, double* ms_per_launch, uint
  * handles; pt_gather_hdr is then called from one thread per handle.  pt_destroy releases the communicator.
  *
  * No communicator call blocks for ever (the reference's Poplar engine has no such failure mode: its IPUs are one
- * device, PathTracerApp.cpp:205-252).  Communicators are non-blocking RCCL communicators; set-up and every exchange
- * are polled against a deadline (pt_comm_set_timeout, default 120000 ms).  slot_items is checked for agreement between
- * the ranks once per communicator and slot size (PT_ERR_INVALID_ARGUMENT on every rank if it differs).  If a peer never
- * joins an exchange (it failed a local check and returned early, crashed, or was never started), if RCCL reports an
- * asynchronous error, or if another thread calls pt_comm_abort(h), the waiting rank aborts its communicator
- * (ncclCommAbort), drains its stream and returns PT_ERR_COMM; the handle then has no communicator and pt_gather_hdr
- * keeps returning PT_ERR_COMM until pt_comm_init_rank / pt_comm_init_all gives it a new one.  CONTRACT for callers
- * pt_comm_init_rank / pt_comm_init_all ask the RCCL they are bound to for its version first (ncclGetVersion): older than
- * 2.14 (no ncclCommInitRankConfig: a non-blocking communicator cannot be made) is refused with PT_ERR_COMM; older than the
- * headers libptmi.so was compiled against, the ncclConfig_t is stamped with the RUNNING library's version, so that library
- * reads exactly the fields it knows (DESIGN.md section 6 says which RCCL each entry point runs on).
- * that drive several ranks: when one rank's call fails, abort the others (pt_comm_abort -- the only pt_* function
+ * device, PathTracerApp.cpp:205-252).  Communicators are asked to be non-blocking and their progress is polled against a
+ * deadline (pt_comm_set_timeout, default 120000 ms); because the RCCL of ROCm 7.2 (2.27.7) does not honour that for set-up
+ * and abort, every RCCL call that may need a peer additionally runs on a worker thread of the handle and is WAITED FOR
+ * against the same deadline: a call that never returns is abandoned.  slot_items is checked for
+ * agreement between the ranks once per communicator and slot size (PT_ERR_INVALID_ARGUMENT on every rank if it differs).
+ * If a peer never joins an exchange (it failed a local check and returned early, crashed, or was never started), if RCCL
+ * reports an asynchronous error, or if another thread calls pt_comm_abort(h), the waiting rank aborts its communicator
+ * (ncclCommAbort, itself bounded), drains its stream and returns PT_ERR_COMM; the handle then has no communicator and
+ * pt_gather_hdr keeps returning PT_ERR_COMM until pt_comm_init_rank / pt_comm_init_all gives it a new one.  CONTRACT for
+ * callers that drive several ranks: when one rank's call fails, abort the others (pt_comm_abort -- the only pt_* function
  * that may be called from another thread while a call on the same handle is in progress) or let them time out.
+ * pt_comm_init_rank / pt_comm_init_all ask the RCCL they are bound to for its version first (ncclGetVersion): older than
+ * 2.14 (no ncclCommInitRankConfig) is refused with PT_ERR_COMM; older than the headers libptmi.so was compiled against,
+ * the ncclConfig_t is stamped with the RUNNING library's version, so that library reads exactly the fields it knows
+ * (pt_runtime_info and DESIGN.md section 6 say which RCCL a process runs on).
  * Multi-rank exchanges have not been run on hardware yet (no multi-GPU box was available): DESIGN.md section 6. */
 enum { PT_HDR_ACCUMULATORS = 0, PT_HDR_FILM = 1 };
 #define PT_COMM_ID_BYTES 128

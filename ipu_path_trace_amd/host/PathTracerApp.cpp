@@ -529,7 +529,7 @@ void PathTracerApp::executeHostFilm(std::uint32_t steps) {
     pt_log::debug_("Path-Trace ms: {}", stats[0].path_trace_ms);
     pt_log::debug_("NIF ms: {}", stats[0].nif_ms);
     pt_log::debug_("Total ms per step: {}", stats[0].total_ms);
-    pt_log::debug_("Step {} took {} samples per pixel from sample index {}", step, stats[0].paths / itemsPerDevice, stats[0].first_sample);
+    pt_log::debug_("Step {} took {} samples per pixel from sample index {}", step, samplesPerIpuStep, stats[0].first_sample);   // (pt_stats.paths counts real pixels only: not padding)
 
     const auto deviceDone = std::chrono::steady_clock::now();
     { pt_trace::Range r("wait_for_host"); hostProcessing.waitForCompletion(); }   // join the previous async task before swapping (:703-708)
