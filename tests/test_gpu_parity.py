@@ -109,6 +109,52 @@ def test_render_bit_exact_under_non_default_options(oracle, ptmi_lib, opts):
     assert got.tobytes() == ref.tobytes()
 
 
+EXTREME_OPTIONS = [
+    dict(W=64, H=48, max_path_length=64, roulette_depth=64, stop_prob=0.05),             # the longest stack the ABI takes, no roulette
+    dict(W=64, H=48, max_path_length=64, roulette_depth=1, stop_prob=0.99),              # roulette weight 1 / (1 - 0.99) on every bounce
+    dict(W=97, H=31, max_path_length=8, fov_degrees=179.0),                              # tan(fov / 2) = 115: almost every ray leaves sideways
+    dict(W=97, H=31, max_path_length=8, fov_degrees=1.0),                                # a pencil of rays at the image centre
+    dict(W=80, H=60, max_path_length=10, refractive_index=1.0),                          # glass that does not bend (r0 = 0)
+    dict(W=80, H=60, max_path_length=10, refractive_index=3.0),                          # total internal reflection almost everywhere
+    dict(W=80, H=60, max_path_length=6, aa_noise_type=2, aa_noise_scale=3.0),            # truncated normal, 3 pixels wide
+    dict(W=80, H=60, max_path_length=6, aa_noise_scale=0.0, sample_precision=1),         # no jitter; 24-bit primary samples
+    dict(W=80, H=60, max_path_length=6, env_rotation_degrees=-725.0, seed=0),            # azimuth far outside one turn, seed 0
+    dict(W=80, H=60, max_path_length=6, seed=2 ** 64 - 1),                               # all seed bits set
+    dict(W=3, H=997, max_path_length=5),                                                 # a sliver of an image
+    dict(W=1, H=1, max_path_length=5),                                                   # one pixel
+]
+
+
+@pytest.mark.parametrize("opts", EXTREME_OPTIONS, ids=lambda o: ",".join("%s=%s" % kv for kv in o.items() if kv[0] not in ("W", "H")) or "tiny")
+def test_render_bit_exact_at_the_extremes_of_the_options(oracle, ptmi_lib, opts):
+    """The same comparison at the ENDS of the option ranges the boundary accepts (pt_create / pt_set_render_settings: depth 1..64,
+    stop-prob in [0, 1), fov in (0, 180) degrees, any refractive index, any seed, any image from 1 x 1): every TraceRecord field
+    identical to the oracle's.  (Reference: the same options of PathTracerApp.cpp:797-817; it has no range checks of its own.)"""
+    O = oracle
+    opts = dict(opts)
+    W, H, spp = opts.pop("W"), opts.pop("H"), 5
+    create = {k: opts[k] for k in ("max_path_length", "roulette_depth", "stop_prob", "refractive_index", "aa_noise_type", "sample_precision") if k in opts}
+    settings = {k: opts[k] for k in ("seed", "aa_noise_scale", "fov_degrees", "env_rotation_degrees") if k in opts}
+    cfg = O.make_config(width=W, height=H, env_rgb=(0.9, 0.8, 1.2), **opts)
+    ref = O.worklist(W, H)
+    st = O.render(cfg, None, ref, 3, spp)                     # (from sample index 3: the cursor below is advanced to it)
+    r = ptmi_lib.Renderer(W, H, iterations_per_batch=2, **create)
+    r.set_constant_env((0.9, 0.8, 1.2))
+    r.init_render_settings(samples_per_step=3, **settings)
+    got = ptmi_lib.worklist(W, H)
+    r.setup(got)
+    r.path_trace()                                            # samples 0..2, thrown away: setup again keeps the sample cursor
+    got = ptmi_lib.worklist(W, H)
+    r.setup(got)
+    r.init_render_settings(samples_per_step=spp, **settings)  # same seed: the sequence continues at sample 3
+    r.path_trace()
+    gst = r.read_results(got)
+    r.close()
+    assert gst.first_sample == 3
+    assert (gst.paths, gst.segments, gst.escaped) == (st.paths, st.segments, st.escaped)
+    assert got.tobytes() == ref.tobytes()
+
+
 def test_render_backward_fold_matches_forward(oracle, ptmi_lib):
     """GPU (forward throughput) against the reference's backward fold (codelets.cpp:255-292): rounding only."""
     O = oracle
