@@ -32,6 +32,7 @@
 #include "pt_nif_f32.h"
 #include "pt_trace.h"
 
+#include "ptmi_comm_worker.h"
 #include "ptmi_context.h"
 #include "ptmi_nif_pack.h"
 #include "ptmi_nif_launch.h"

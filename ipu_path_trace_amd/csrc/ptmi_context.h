@@ -47,8 +47,6 @@ struct HostLayer {
 
 }  // namespace
 
-struct CommWorker;   // ptmi_film_comm.h: the long-lived thread that makes a handle's RCCL calls
-
 struct pt_context {
   pt_config cfg{};
   std::string error;
@@ -159,7 +157,7 @@ struct pt_context {
 
   // multi-GPU film hand-off: RCCL communicator (one rank per handle) and the HDR tile buffers
   ncclComm_t comm = nullptr;
-  std::shared_ptr<CommWorker> comm_worker;   // created with the first communicator call; dropped when a call never returns
+  std::shared_ptr<ptw::BoundedWorker> comm_worker;   // the long-lived thread that makes the handle's RCCL calls (ptmi_comm_worker.h): created with the first communicator call, dropped when a call never returns
   int comm_rank = 0, comm_world = 1;
   bool comm_broken = false;                  // the communicator was aborted (deadline, peer failure, pt_comm_abort): gathers fail until a new one is made
   std::atomic<bool> comm_abort_req{false};   // pt_comm_abort from another thread: the polling loops see it and abort

@@ -36,95 +36,26 @@
     }                                                                                        \
   } while (0)
 
-using comm_clock = std::chrono::steady_clock;
+using comm_clock = ptw::clock;
+using CommJob = ptw::BoundedJob;        // .result holds an ncclResult_t, .made the ncclComm_t's a set-up job is making
+using CommWorker = ptw::BoundedWorker;  // (the machinery and why the worker is long-lived: ptmi_comm_worker.h)
 
-static void comm_backoff(unsigned& spins) {
-  if (++spins < 200) std::this_thread::yield();
-  else std::this_thread::sleep_for(std::chrono::microseconds(spins < 2000 ? 50 : 500));
-}
+static void comm_backoff(unsigned& spins) { ptw::backoff(spins); }
+static inline bool nccl_ok(int r) { return r == ncclSuccess || r == ncclInProgress; }
 
-static inline bool nccl_ok(ncclResult_t r) { return r == ncclSuccess || r == ncclInProgress; }
-
-// One RCCL call (or group of calls) on the handle's worker thread.  RUNNING -> DONE by the worker, RUNNING -> ABANDONED by
-// the waiter (one compare-exchange decides who owns the outcome); a worker that finds its job abandoned releases what it made.
-struct CommJob {
-  enum : int { RUNNING = 0, DONE = 1, ABANDONED = 2 };
-  std::atomic<int> state{RUNNING};
-  ncclResult_t result = ncclSuccess;
-  std::string failed_call;                 // which call of a group failed
-  std::vector<ncclComm_t> comms;           // set-up jobs: the communicators being made (written by RCCL as soon as it has one)
-};
-
-// The worker: ONE long-lived thread per handle makes all of the handle's RCCL calls.  Long-lived on purpose: with a
-// non-blocking communicator an RCCL call leaves an asynchronous job behind whose bookkeeping lives in the CALLING thread's
-// thread-local storage (group.cc), so the calling thread has to outlive the communicator -- a thread per call aborted the
-// process in the first gather.  A worker whose call never returns is dropped by the handle (the next call gets a new
-// worker); it parks or stays blocked until the process ends.  After an orderly ncclCommDestroy the worker is told to exit.
-struct CommWorker {
-  std::mutex m;
-  std::condition_variable cv;
-  std::deque<std::function<void()>> jobs;
-  bool quit = false;
-  static void loop(std::shared_ptr<CommWorker> self) {
-    for (;;) {
-      std::function<void()> f;
-      {
-        std::unique_lock<std::mutex> lk(self->m);
-        self->cv.wait(lk, [&] { return self->quit || !self->jobs.empty(); });
-        if (self->jobs.empty()) return;
-        f = std::move(self->jobs.front());
-        self->jobs.pop_front();
-      }
-      f();
-    }
-  }
-  void post(std::function<void()> f) {
-    { std::lock_guard<std::mutex> lk(m); jobs.push_back(std::move(f)); }
-    cv.notify_one();
-  }
-  void stop() {
-    { std::lock_guard<std::mutex> lk(m); quit = true; }
-    cv.notify_one();
-  }
-};
-
-static std::shared_ptr<CommWorker> comm_worker(pt_handle h) {
-  if (!h->comm_worker) {
-    h->comm_worker = std::make_shared<CommWorker>();
-    std::thread(CommWorker::loop, h->comm_worker).detach();
-  }
-  return h->comm_worker;
-}
-
+// An RCCL call (or group of calls) on the handle's worker thread; fn(job) returns the ncclResult_t.  A set-up call that comes
+// back after it was abandoned has its communicators aborted by the worker itself.
 template <class F>
 static std::shared_ptr<CommJob> comm_start(pt_handle h, size_t n_comms, F fn) {
-  auto job = std::make_shared<CommJob>();
-  job->comms.assign(n_comms, nullptr);
   const int device = h->cfg.device;
-  comm_worker(h)->post([job, device, fn]() mutable {
-    (void)hipSetDevice(device);
-    job->result = fn(*job);
-    int expected = CommJob::RUNNING;
-    if (!job->state.compare_exchange_strong(expected, CommJob::DONE))
-      for (ncclComm_t c : job->comms) if (c) (void)ncclCommAbort(c);   // nobody waits any more: release the late arrival
-  });
-  return job;
+  return ptw::bounded_start(h->comm_worker, n_comms,
+                            [device, fn](CommJob& j) mutable { (void)hipSetDevice(device); return (int)fn(j); },
+                            [](CommJob& j) { for (void* c : j.made) if (c) (void)ncclCommAbort(static_cast<ncclComm_t>(c)); });
 }
 
-// Wait for a job against a deadline (and pt_comm_abort).  true: the job is DONE and its result is the caller's;
-// false: it was abandoned -- the worker owns whatever the call still makes, and the handle lets go of that worker.
+// Wait for a job against a deadline (and pt_comm_abort).  false: abandoned -- the handle has let go of that worker.
 static bool comm_join(pt_handle h, CommJob& job, comm_clock::time_point deadline, bool heed_abort_request = true) {
-  unsigned spins = 0;
-  for (;;) {
-    if (job.state.load(std::memory_order_acquire) == CommJob::DONE) return true;
-    if ((heed_abort_request && h->comm_abort_req.load()) || comm_clock::now() > deadline) {
-      int expected = CommJob::RUNNING;
-      if (!job.state.compare_exchange_strong(expected, CommJob::ABANDONED)) return true;   // lost the race: it finished just now
-      h->comm_worker.reset();
-      return false;
-    }
-    comm_backoff(spins);
-  }
+  return ptw::bounded_join(h->comm_worker, job, deadline, heed_abort_request ? &h->comm_abort_req : nullptr);
 }
 
 // ncclCommAbort, bounded: it is a blocking call too (see (2) above).  Returns whether the abort has completed; if not it
@@ -222,7 +153,7 @@ template <class F>
 static int comm_exchange(pt_handle h, const char* what, comm_clock::time_point deadline, F fn) {
   auto job = comm_start(h, 0, fn);
   if (!comm_join(h, *job, deadline)) return comm_fail(h, comm_no_progress(h, what) + "; the RCCL call is still blocked and was left behind");
-  if (!nccl_ok(job->result)) return comm_fail(h, std::string(what) + ": " + job->failed_call + ": " + ncclGetErrorString(job->result));
+  if (!nccl_ok(job->result)) return comm_fail(h, std::string(what) + ": " + job->failed_call + ": " + ncclGetErrorString((ncclResult_t)job->result));
   if (int rc = comm_wait_host(h, what, deadline)) return rc;     // peers connected, transfer queued on the stream
   return comm_wait_stream(h, what, deadline);                    // transfer done (or the communicator aborted)
 }
@@ -348,17 +279,17 @@ int pt_comm_init_rank(pt_handle h, const void* id_in, int rank, int world) {
   // a rank that never arrives ends here, not in a hang: whether RCCL returns at once (non-blocking honoured: the polled wait
   // below sees the deadline) or stays inside the call until every rank has checked in (then comm_join does)
   auto job = comm_start(h, 1, [id, rank, world, cfg](CommJob& j) mutable {
-    return ncclCommInitRankConfig(&j.comms[0], world, id, rank, &cfg);
+    return ncclCommInitRankConfig(reinterpret_cast<ncclComm_t*>(&j.made[0]), world, id, rank, &cfg);
   });
   if (!comm_join(h, *job, deadline)) {
     h->comm_broken = true;
     h->comm_abort_req.store(false);
     return fail(h, PT_ERR_COMM, comm_no_progress(h, "communicator set-up") + "; ncclCommInitRankConfig is still blocked and was left behind -- communicator aborted");
   }
-  ncclComm_t comm = job->comms[0];
+  ncclComm_t comm = static_cast<ncclComm_t>(job->made[0]);
   if (!nccl_ok(job->result)) {
     (void)comm_abort_bounded(h, comm);
-    return fail(h, PT_ERR_COMM, std::string("ncclCommInitRankConfig: ") + ncclGetErrorString(job->result));
+    return fail(h, PT_ERR_COMM, std::string("ncclCommInitRankConfig: ") + ncclGetErrorString((ncclResult_t)job->result));
   }
   h->comm = comm;
   if (int rc = comm_wait_host(h, "communicator set-up", deadline)) return rc;
@@ -395,7 +326,7 @@ int pt_comm_init_all(pt_handle* handles, int n) {
     r = ncclGroupStart();
     if (!nccl_ok(r)) { j.failed_call = "ncclGroupStart"; return r; }
     for (int i = 0; i < n; ++i) {
-      r = (hipSetDevice(devs[i]) == hipSuccess) ? ncclCommInitRankConfig(&j.comms[i], n, id, i, &cfg) : ncclUnhandledCudaError;
+      r = (hipSetDevice(devs[i]) == hipSuccess) ? ncclCommInitRankConfig(reinterpret_cast<ncclComm_t*>(&j.made[i]), n, id, i, &cfg) : ncclUnhandledCudaError;
       if (!nccl_ok(r)) { j.failed_call = "ncclCommInitRankConfig"; (void)ncclGroupEnd(); return r; }
     }
     r = ncclGroupEnd();
@@ -404,9 +335,10 @@ int pt_comm_init_all(pt_handle* handles, int n) {
   });
   if (!comm_join(h, *job, deadline))
     return fail(h, PT_ERR_COMM, comm_no_progress(h, "communicator set-up") + "; the RCCL call is still blocked and was left behind");
-  std::vector<ncclComm_t> comms = job->comms;
+  std::vector<ncclComm_t> comms;
+  for (void* c : job->made) comms.push_back(static_cast<ncclComm_t>(c));
   auto abort_all = [&]() { for (int i = 0; i < n; ++i) (void)comm_abort_bounded(handles[i], comms[i]); };
-  if (!nccl_ok(job->result)) { abort_all(); return fail(h, PT_ERR_COMM, job->failed_call + ": " + ncclGetErrorString(job->result)); }
+  if (!nccl_ok(job->result)) { abort_all(); return fail(h, PT_ERR_COMM, job->failed_call + ": " + ncclGetErrorString((ncclResult_t)job->result)); }
   unsigned spins = 0;
   for (int i = 0; i < n;) {
     ncclResult_t st = ncclSuccess;
