@@ -394,3 +394,31 @@ def test_out_of_memory_is_its_own_status(ptmi_lib):
     r.path_trace()
     assert r.read_results(rec).paths == 32 * 32 * 2
     r.close()
+
+
+def test_uint16_record_fields_at_their_limits(oracle, ptmi_lib):
+    """TraceRecord::sampleCount and ::pathLength are uint16 (TraceRecord.hpp:10-11).  65535 samples in one step is the most the
+    boundary accepts (65536 would wrap sampleCount to 0 and the host divides by it, AccumulatedImage.cpp:69-71): sampleCount
+    comes back as 65535, pathLength -- about 1.6 x 65535 path segments per pixel -- WRAPS exactly as the reference's field does,
+    pt_stats.segments keeps the exact 64-bit total, and every radiance sum (65535 fp32 additions per pixel, in sample order)
+    equals the oracle's bit for bit."""
+    W = H = 12
+    spp = 65535
+    r = ptmi_lib.Renderer(W, H, max_path_length=8)
+    r.set_constant_env((0.5, 1.0, 0.25))
+    with pytest.raises(ptmi_lib.PtError):
+        r.init_render_settings(samples_per_step=65536)
+    r.init_render_settings(samples_per_step=spp)
+    got = ptmi_lib.worklist(W, H)
+    r.setup(got)
+    r.path_trace()
+    st = r.read_results(got)
+    r.close()
+    cfg = oracle.make_config(width=W, height=H, max_path_length=8, env_rgb=(0.5, 1.0, 0.25), fold=oracle.FOLD_FORWARD)
+    ref = oracle.worklist(W, H)
+    ost = oracle.render(cfg, None, ref, 0, spp)
+    assert (st.paths, st.segments, st.escaped) == (ost.paths, ost.segments, ost.escaped) and st.paths == W * H * spp
+    assert st.segments > 65535 * W * H                                  # more segments than the 16-bit fields can count per pixel ...
+    assert (got["sampleCount"] == 65535).all()
+    assert got.tobytes() == ref.tobytes()                               # ... and the wrapped pathLength equals the oracle's, as do the sums
+    assert int(got["pathLength"].astype(np.int64).sum()) != st.segments  # the wire field really wrapped
