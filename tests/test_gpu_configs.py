@@ -314,3 +314,64 @@ def test_configs_at_their_stated_sizes_and_sample_counts(oracle, ptmi_lib, name,
     assert np.array_equal(got["pathLength"], ref["pathLength"]), name
     for c in "rgb":
         np.testing.assert_allclose(got[c], ref[c], rtol=NIF_RTOL, atol=1e-5, err_msg=name)
+
+
+def test_full_size_radiance_is_linear_in_the_environment_and_additive_over_steps(ptmi_lib):
+    """Size-independent properties at BASELINE's full image (1104 x 1000, depth 8), no oracle needed: with a constant sky the
+    accumulated radiance is env (.) throughput summed over the samples, so (a) doubling the environment doubles every
+    accumulator EXACTLY (a power of two commutes with every fp32 rounding), (b) an environment with one channel carries
+    nothing in the other two, (c) one step of 16 samples per pixel equals two steps of 8 bit for bit (the sample sequence and
+    each pixel's summation order do not depend on how the samples are cut into steps: codelets.cpp:295-300), and path structure
+    (pathLength, sampleCount) does not depend on the environment at all."""
+    W, H, depth = 1104, 1000, 8
+
+    def render(env, steps):
+        r = ptmi_lib.Renderer(W, H, max_path_length=depth)
+        r.set_constant_env(env)
+        rec = ptmi_lib.worklist(W, H)
+        r.setup(rec)
+        for spp in steps:
+            r.init_render_settings(seed=5, samples_per_step=spp)
+            r.path_trace()
+        r.read_results(rec)
+        r.close()
+        return rec
+
+    one = render((0.75, 0.5, 1.25), [16])
+    two = render((1.5, 1.0, 2.5), [16])
+    for c in "rgb":
+        assert np.array_equal(two[c], one[c] * np.float32(2.0)), c
+    assert np.array_equal(two["pathLength"], one["pathLength"]) and np.array_equal(two["sampleCount"], one["sampleCount"])
+    red = render((0.75, 0.0, 0.0), [16])
+    assert np.array_equal(red["r"], one["r"]) and not red["g"].any() and not red["b"].any()
+    split = render((0.75, 0.5, 1.25), [8, 8])
+    assert split.tobytes() == one.tobytes()
+    assert one["r"].max() > 0 and (one["pathLength"] > 16).any()
+
+
+def test_full_size_nif_radiance_scales_with_the_decode_constant(ptmi_lib):
+    """The same kind of property through the NIF stage at the full C2 shape (6 x 320 fp16 network, 1104 x 1000, depth 8): with a
+    linear decode (log_tonemap = 0) and a zero mean the decoded environment is o x max (NifModel.cpp:226-233), so doubling `max`
+    doubles every accumulated radiance EXACTLY -- through the fused head, the BGR -> RGB x throughput product
+    (codelets.cpp:366-382) and the accumulate pass -- while the path structure stays what it was."""
+    W, H, depth, spp = 1104, 1000, 8, 8
+    layers = nif_assets.synthetic_nif()
+
+    def render(max_value):
+        r = ptmi_lib.Renderer(W, H, max_path_length=depth)
+        r.init_nif_weights(layers, 12, max_value, [0.0, 0.0, 0.0], log_tonemap=False)
+        r.init_render_settings(seed=9, samples_per_step=spp)
+        rec = ptmi_lib.worklist(W, H)
+        r.setup(rec)
+        r.path_trace()
+        st = r.read_results(rec)
+        r.close()
+        return rec, st
+
+    a, sa = render(1.5)
+    b, sb = render(3.0)
+    assert (sa.paths, sa.segments, sa.escaped) == (sb.paths, sb.segments, sb.escaped) and sa.escaped > 0.9 * sa.paths
+    assert np.array_equal(a["pathLength"], b["pathLength"])
+    for c in "rgb":
+        assert np.isfinite(a[c]).all() and np.abs(a[c]).max() > 0
+        assert np.array_equal(b[c], a[c] * np.float32(2.0)), c
