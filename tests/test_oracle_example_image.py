@@ -180,3 +180,44 @@ def test_reflect_and_refract_against_the_inside_of_the_mirror_and_glass_spheres(
     assert abs(water_iou - glass_iou) < 0.1, (water_iou, glass_iou)           # 1.33 and 1.5 are NOT told apart by this picture
     dense_iou, _ = _interior_scores(oracle, f, "glass", 2, fov, refractive_index=2.0)
     assert dense_iou < glass_iou                                              # ... but the index is not free either
+
+
+def test_oracle_refraction_against_an_independent_numpy_restatement(oracle):
+    """orc_specular_ids' walk through the glass sphere (enter: refract with eta = 1/n, leave: refract with eta = n, Snell in
+    vector form, total internal reflection reflects) restated in numpy in float64, independently of the oracle's C: the set of
+    pixels that see the floor THROUGH the glass sphere agrees for the scene's index and for another one.  (Differences are
+    confined to the silhouettes of the small spheres the numpy version ignores and to boundary pixels.)"""
+    from scipy import ndimage
+    W, H, fov = 882, 720, np.radians(81.0)
+    inside = ndimage.binary_erosion(oracle.object_ids(W, H, fov) == 2, iterations=6)
+    ys, xs = np.nonzero(inside)
+    tx = np.tan(fov / 2)
+    ty = (H / W) * tx
+    d = np.stack([((2 * xs - W) / W) * tx, -(((2 * ys - H) / H) * ty), -np.ones(xs.size)], 1)
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    C, R = np.array([1.9929, -1.08666, -3.23]), 0.5                     # codelets.cpp:114
+
+    def sphere_t(o, dirs, near):
+        oc = o - C
+        b = 2 * (oc * dirs).sum(1)
+        disc = np.sqrt(np.maximum(b * b - 4 * ((oc * oc).sum(1) - R * R), 0))
+        return (-b - disc) / 2 if near else (-b + disc) / 2
+
+    def bend(dirs, n, eta):                                              # n faces against dirs
+        c1 = -(n * dirs).sum(1)
+        c2 = 1 - eta * eta * (1 - c1 * c1)
+        out = np.where((c2 <= 0)[:, None], dirs + n * (2 * c1)[:, None], dirs * eta + n * (eta * c1 - np.sqrt(np.maximum(c2, 0)))[:, None])
+        return out / np.linalg.norm(out, axis=1)[:, None]
+
+    for index in (1.5, 1.33):
+        p = d * sphere_t(np.zeros_like(d), d, True)[:, None]
+        d1 = bend(d, (p - C) / R, 1 / index)
+        p2 = p + d1 * sphere_t(p + d1 * 1e-6, d1, False)[:, None]
+        d2 = bend(d1, -(p2 - C) / R, index)
+        t = (-1.6 - p2[:, 1]) / d2[:, 1]                                 # the disc's plane (codelets.cpp:121)
+        q = p2 + d2 * t[:, None]
+        floor = np.zeros((H, W), dtype=bool)
+        floor[ys, xs] = (t > 0) & (q[:, 0] ** 2 + (q[:, 2] + 5.22) ** 2 <= 3.5 ** 2)
+        ids, _ = oracle.specular_ids(W, H, fov, refractive_index=index)
+        agree = ((ids == 5) == floor)[inside].mean()
+        assert agree > 0.985, (index, agree)
