@@ -221,6 +221,15 @@ def test_bench_takes_the_real_n_rank_branch_at_world_size_one(tmp_path):
     assert out["config"]["hdr_gather"] == "pt_gather_hdr (RCCL inside libptmi.so)"
     assert np.load(env_film).tobytes() == np.load(plain).tobytes()
 
+    # C4's job shape on the same branch: a save interval, tiles re-dealt by measured path length (the all-reduce of the tile
+    # costs on a CUDA tensor, pt_tile_costs, pt_setup of the new worklist), one product gather per interval
+    shaped, shaped_plain = str(tmp_path / "shaped.npy"), str(tmp_path / "shaped_plain.npy")
+    interval = ["--save-interval", "1"]
+    out = _bench_line(common + interval + ["--dump-film", shaped_plain])
+    out = _bench_line(common + interval + ["--dist", "--enable-load-balancing", "--dump-film", shaped])
+    assert out["config"]["hdr_gather"] == "pt_gather_hdr (RCCL inside libptmi.so)" and out["config"]["load_balancing"] is True
+    assert np.load(shaped).tobytes() == np.load(shaped_plain).tobytes()
+
     fallback = str(tmp_path / "fallback.npy")
     out = _bench_line(common + ["--dist", "--comm-fault", "corrupt-id", "--comm-timeout-ms", "8000", "--dump-film", fallback])
     assert out["config"]["hdr_gather"].startswith("torch.distributed gather (pt_comm_init_rank failed"), out["config"]
